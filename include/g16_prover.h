@@ -1,0 +1,147 @@
+/*
+ * g16_prover.h -- C ABI of libg16hip.so, the MI355X (gfx950) Groth16 prover for snarkjs-format
+ * proving keys.  This is the drop-in boundary: plain pointers and sizes,
+ * no C++ or torch types, no exceptions across the boundary.
+ *
+ * What each entry point replaces.  The reference repo has no prover source; the path lives in
+ * the npm packages it pins (never vendored):
+ *     snarkjs 0.4.12        /root/reference/yarn.lock:987-1001   (package.json:12)
+ *     ffjavascript 0.2.48   /root/reference/yarn.lock:408-416
+ *     wasmcurves 0.1.0      /root/reference/yarn.lock:1132-1138
+ *     @iden3/binfileutils   /root/reference/yarn.lock:10-16
+ * and the only snarkjs call sites in the reference are the CLI lines /root/reference/Makefile:30-33.
+ * The [EXT] names below are the published functions of those packages.
+ *
+ * Conventions
+ *   - return 0 on success, negative G16_E_* on failure; g16_last_error() gives the text
+ *     (thread-local; for input errors the text is snarkjs's own Error message).
+ *   - the caller owns every buffer it passes; the library copies what it keeps.
+ *   - field elements are 32 bytes little-endian.  Proof points come out affine in STANDARD
+ *     (non-Montgomery) form: that is what snarkjs `G1.toObject` stringifies.
+ *   - one in-flight call per g16_prover handle; different handles may be used concurrently.
+ */
+#ifndef G16_PROVER_H
+#define G16_PROVER_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define G16_OK 0
+#define G16_E_ARG (-1)    /* bad argument */
+#define G16_E_FORMAT (-2) /* malformed zkey/wtns (message = snarkjs's) */
+#define G16_E_HIP (-3)    /* HIP runtime error */
+#define G16_E_NOGPU (-4)  /* no gfx950 device / extension cannot run: never falls back to CPU */
+#define G16_E_STATE (-5)
+
+typedef struct g16_prover g16_prover;
+
+typedef struct g16_opts {
+  int32_t device;       /* HIP device ordinal */
+  int32_t shard_rank;   /* this handle owns point range [rank*n/count, (rank+1)*n/count) of every */
+  int32_t shard_count;  /* base section; 0/1 = whole key                               */
+  int32_t window_bits;  /* Pippenger window c (0 = auto)                                           */
+  int32_t task_len;     /* max sorted entries per bucket-accumulation task (0 = auto)              */
+  uint32_t flags;       /* reserved, 0 */
+} g16_opts;
+
+typedef struct g16_proof {
+  uint8_t a[64];  /* pi_a: x | y                      */
+  uint8_t b[128]; /* pi_b: x.c0 | x.c1 | y.c0 | y.c1  */
+  uint8_t c[64];  /* pi_c: x | y                      */
+} g16_proof;      /* infinity = all-zero bytes        */
+
+typedef struct g16_info {
+  uint32_t n_vars, n_public, domain_size, n_coefs;
+  uint32_t n_a, n_b1, n_b2, n_c, n_h; /* non-infinity bases resident per MSM (this shard) */
+  uint32_t window_bits[5];            /* c chosen for A, B1, B2, C, H */
+} g16_info;
+
+/* Per-phase device timings of the last g16_prove* on this handle, milliseconds (HIP events on the
+ * prover's stream).  msm[] order: A, B1, B2, C, H.  *_kernel_ms are the bucket-accumulate kernels
+ * alone (the roofline kernel of bench.py). */
+typedef struct g16_timings {
+  float upload_ms, qap_ms, ntt_ms, msm_ms[5], tail_ms, total_ms;
+  float msm_accum_kernel_ms[5];
+} g16_timings;
+
+/* [EXT] snarkjs groth16_prove.js: readBinFile(zkey,"zkey",2) + zkey_utils.readHeader + the
+ * section reads 4..9 of groth16.prove.  Parses and validates, regroups section 4 into CSR,
+ * uploads coefficients and (this shard's) bases to HBM once, builds NTT tables.
+ * Errors: "<name>: Invalid File format", "Version not supported", "zkey file is not groth16". */
+int g16_create(const uint8_t* zkey, size_t zkey_len, const g16_opts* opts, g16_prover** out);
+
+/* [EXT] snarkjs groth16.prove(zkey, wtns): buildABC1 -> 3x(Fr.ifft, batchApplyKey, Fr.fft) ->
+ * joinABC -> 5x multiExpAffine -> blinding -> toAffine.  r, s: 32-byte LE scalars < r, or NULL
+ * for the OS CSPRNG (snarkjs: Fr.random()).  pub receives n_public * 32 bytes (w[1..p]).
+ * Errors: "Curve of the witness does not match the curve of the proving key",
+ *         "Invalid witness length. Circuit: N, witness: M". */
+int g16_prove(g16_prover* p, const uint8_t* wtns, size_t wtns_len, const uint8_t r[32],
+              const uint8_t s[32], g16_proof* out, uint8_t* pub);
+
+/* Batch of independent witnesses against the resident key (BASELINE config 3).  rs: count*64
+ * bytes (r|s per proof) or NULL; pub: count*n_public*32 bytes or NULL. */
+int g16_prove_batch(g16_prover* p, const uint8_t* const* wtns, const size_t* wtns_lens, size_t count,
+                    const uint8_t* rs, g16_proof* out, uint8_t* pub);
+
+/* HBM-resident witness slots: g16_stage_witness parses + uploads (the PCIe leg), g16_prove_staged
+ * runs the device pipeline on a staged slot -- bench.py times the latter ("inputs already
+ * resident in HBM").  Slots are created on demand; staging the same slot again overwrites it. */
+int g16_stage_witness(g16_prover* p, uint32_t slot, const uint8_t* wtns, size_t wtns_len);
+int g16_prove_staged(g16_prover* p, uint32_t slot, const uint8_t r[32], const uint8_t s[32],
+                     g16_proof* out, uint8_t* pub);
+
+/* Multi-GPU: a sharded handle computes its partial MSM sums; the host exchanges the
+ * G16_PARTIAL_BYTES blobs (RCCL all-gather of bytes) and any rank finishes the proof.
+ * partials = count blobs back to back, one per shard rank. */
+#define G16_PARTIAL_BYTES (128 * 4 + 256) /* XYZZ sums A,B1,C,H (G1) + B2 (G2), Montgomery */
+int g16_prove_partial(g16_prover* p, uint32_t slot, uint8_t partial[G16_PARTIAL_BYTES]);
+int g16_prove_finish(g16_prover* p, uint32_t slot, const uint8_t* partials, uint32_t count,
+                     const uint8_t r[32], const uint8_t s[32], g16_proof* out, uint8_t* pub);
+
+int g16_get_info(const g16_prover* p, g16_info* out);
+int g16_get_timings(const g16_prover* p, g16_timings* out);
+void g16_destroy(g16_prover* p);
+const char* g16_last_error(void);
+
+/* Operator-level entry points, the device twins of ffjavascript's public curve API [EXT]:
+ *   g16_fr_fft / g16_fr_ifft          Fr.fft / Fr.ifft   (n Montgomery residues, natural order,
+ *                                     in place; ifft includes 1/n)
+ *   g16_g1_multiexp / g16_g2_multiexp G1/G2.multiExpAffine(bases LEM affine, scalars standard LE)
+ *                                     -> affine STANDARD-form point (64 / 128 bytes)
+ *   g16_fr_batch_mul                  Montgomery products out[i] = a[i]*b[i]  (frm_mul)        */
+int g16_fr_fft(int device, uint8_t* buf, size_t n);
+int g16_fr_ifft(int device, uint8_t* buf, size_t n);
+int g16_fr_batch_mul(int device, const uint8_t* a, const uint8_t* b, uint8_t* out, size_t n, int field /*0 Fr, 1 Fq*/);
+/* Layer tests: elementwise field op (op: 0 mul, 1 add, 2 sub, 3 toMontgomery, 4 fromMontgomery,
+ * 5 neg; field 0 = Fr, 1 = Fq; raw 32-byte images in and out) and elementwise affine point addition
+ * a[i]+b[i] on the device (curve 1 = G1, 2 = G2; LEM affine in, STANDARD affine out). */
+int g16_field_op(int device, int field, int op, const uint8_t* a, const uint8_t* b, uint8_t* out, size_t n);
+int g16_ec_add(int device, int curve, const uint8_t* a, const uint8_t* b, uint8_t* out, size_t n);
+int g16_g1_multiexp(int device, const uint8_t* bases, const uint8_t* scalars, size_t n,
+                    int window_bits, uint8_t out[64]);
+int g16_g2_multiexp(int device, const uint8_t* bases, const uint8_t* scalars, size_t n,
+                    int window_bits, uint8_t out[128]);
+
+/* Test-only trapdoor setup over a shape-matched synthetic R1CS (the real nzcp_live
+ * R1CS cannot be produced offline).  Host-only (no GPU needed).  Emits a snarkjs-layout .zkey and
+ * .wtns plus the verification key points (alpha1 | beta2 | gamma2 | delta2 | IC[0..p], affine
+ * Montgomery LE, 64/128 bytes each).  Buffers are malloc'd; release with g16_free.
+ * Generator spec: oracle/synth.py docstring (both sides follow the same draw order). */
+int g16_synth_setup(uint32_t n_vars, uint32_t n_public, uint32_t n_constraints, uint64_t seed,
+                    int threads, uint8_t** zkey, size_t* zkey_len, uint8_t** wtns, size_t* wtns_len,
+                    uint8_t** vkey, size_t* vkey_len);
+/* A fresh satisfying witness for the same synthetic circuit (batch mode, BASELINE config 3): the
+ * free wires are redrawn from `wseed`, the slack wires re-solved; the circuit stays that of `seed`.
+ * g16_synth_setup uses wseed = seed.  Returns a .wtns image. */
+int g16_synth_witness(uint32_t n_vars, uint32_t n_public, uint32_t n_constraints, uint64_t seed,
+                      uint64_t wseed, uint8_t** wtns, size_t* wtns_len);
+void g16_free(void* p);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* G16_PROVER_H */

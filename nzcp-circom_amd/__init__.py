@@ -1,0 +1,247 @@
+"""nzcp-circom_amd -- MI355X-native Groth16 prover for the compiled NZCP circuits.
+
+This Python module is PLUMBING: a ctypes binding over the C ABI of libg16hip.so
+(include/g16_prover.h) used by tests/ and bench.py.  The product host is the Node.js shim in
+nzcp-circom_amd/js (snarkjs-shaped `groth16.prove`); both sit on the same C ABI.
+
+There is no CPU fallback: `load()` raises if the shared library is missing, and every compute
+entry point returns G16_E_NOGPU (raised here as G16Error) when no HIP device is present.
+The API mirrors snarkjs 0.4.12 `groth16.prove` (pin /root/reference/yarn.lock:987-1001):
+`Prover(zkey).prove(wtns, r, s) -> (proof_dict, public_signals)` with snarkjs's JSON shapes and
+error messages.
+"""
+import ctypes as C
+import json
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libg16hip.so")
+PARTIAL_BYTES = 128 * 4 + 256
+
+_lib = None
+
+
+class G16Error(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(msg)
+        self.code = code
+
+
+class Opts(C.Structure):
+    _fields_ = [("device", C.c_int32), ("shard_rank", C.c_int32), ("shard_count", C.c_int32),
+                ("window_bits", C.c_int32), ("task_len", C.c_int32), ("flags", C.c_uint32)]
+
+
+class Proof(C.Structure):
+    _fields_ = [("a", C.c_uint8 * 64), ("b", C.c_uint8 * 128), ("c", C.c_uint8 * 64)]
+
+
+class Info(C.Structure):
+    _fields_ = [("n_vars", C.c_uint32), ("n_public", C.c_uint32), ("domain_size", C.c_uint32),
+                ("n_coefs", C.c_uint32), ("n_a", C.c_uint32), ("n_b1", C.c_uint32),
+                ("n_b2", C.c_uint32), ("n_c", C.c_uint32), ("n_h", C.c_uint32),
+                ("window_bits", C.c_uint32 * 5)]
+
+
+class Timings(C.Structure):
+    _fields_ = [("upload_ms", C.c_float), ("qap_ms", C.c_float), ("ntt_ms", C.c_float),
+                ("msm_ms", C.c_float * 5), ("tail_ms", C.c_float), ("total_ms", C.c_float),
+                ("msm_accum_kernel_ms", C.c_float * 5)]
+
+
+EXPORTS = ["g16_create", "g16_prove", "g16_prove_batch", "g16_stage_witness", "g16_prove_staged",
+           "g16_prove_partial", "g16_prove_finish", "g16_get_info", "g16_get_timings", "g16_destroy",
+           "g16_last_error", "g16_fr_fft", "g16_fr_ifft", "g16_fr_batch_mul", "g16_field_op",
+           "g16_ec_add", "g16_g1_multiexp", "g16_g2_multiexp", "g16_synth_setup",
+           "g16_synth_witness", "g16_free"]
+
+
+def load():
+    """dlopen libg16hip.so; fails loudly when it has not been built (no fallback)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise G16Error(-4, f"{LIB_PATH} not built: run `python -c 'import __graft_entry__ as g; g.build()'`")
+    lib = C.CDLL(LIB_PATH)
+    u8p, sz, vp = C.POINTER(C.c_uint8), C.c_size_t, C.c_void_p
+    lib.g16_last_error.restype = C.c_char_p
+    lib.g16_create.argtypes = [C.c_char_p, sz, C.POINTER(Opts), C.POINTER(vp)]
+    lib.g16_prove.argtypes = [vp, C.c_char_p, sz, C.c_char_p, C.c_char_p, C.POINTER(Proof), C.c_char_p]
+    lib.g16_stage_witness.argtypes = [vp, C.c_uint32, C.c_char_p, sz]
+    lib.g16_prove_staged.argtypes = [vp, C.c_uint32, C.c_char_p, C.c_char_p, C.POINTER(Proof), C.c_char_p]
+    lib.g16_prove_partial.argtypes = [vp, C.c_uint32, C.c_char_p]
+    lib.g16_prove_finish.argtypes = [vp, C.c_uint32, C.c_char_p, C.c_uint32, C.c_char_p, C.c_char_p,
+                                     C.POINTER(Proof), C.c_char_p]
+    lib.g16_prove_batch.argtypes = [vp, C.POINTER(C.c_char_p), C.POINTER(sz), sz, C.c_char_p,
+                                    C.POINTER(Proof), C.c_char_p]
+    lib.g16_get_info.argtypes = [vp, C.POINTER(Info)]
+    lib.g16_get_timings.argtypes = [vp, C.POINTER(Timings)]
+    lib.g16_destroy.argtypes = [vp]
+    lib.g16_destroy.restype = None
+    lib.g16_fr_fft.argtypes = [C.c_int, C.c_char_p, sz]
+    lib.g16_fr_ifft.argtypes = [C.c_int, C.c_char_p, sz]
+    lib.g16_fr_batch_mul.argtypes = [C.c_int, C.c_char_p, C.c_char_p, C.c_char_p, sz, C.c_int]
+    lib.g16_field_op.argtypes = [C.c_int, C.c_int, C.c_int, C.c_char_p, C.c_char_p, C.c_char_p, sz]
+    lib.g16_ec_add.argtypes = [C.c_int, C.c_int, C.c_char_p, C.c_char_p, C.c_char_p, sz]
+    lib.g16_g1_multiexp.argtypes = [C.c_int, C.c_char_p, C.c_char_p, sz, C.c_int, C.c_char_p]
+    lib.g16_g2_multiexp.argtypes = [C.c_int, C.c_char_p, C.c_char_p, sz, C.c_int, C.c_char_p]
+    lib.g16_synth_setup.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint64, C.c_int,
+                                    C.POINTER(vp), C.POINTER(sz), C.POINTER(vp), C.POINTER(sz),
+                                    C.POINTER(vp), C.POINTER(sz)]
+    lib.g16_synth_witness.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint64, C.c_uint64,
+                                      C.POINTER(vp), C.POINTER(sz)]
+    lib.g16_free.argtypes = [vp]
+    lib.g16_free.restype = None
+    _lib = lib
+    return lib
+
+
+def _check(rc):
+    if rc != 0:
+        raise G16Error(rc, load().g16_last_error().decode("utf-8", "replace"))
+
+
+def _take(ptr, n):
+    """Copy a malloc'd buffer into bytes and free it."""
+    data = C.string_at(ptr.value, n.value)
+    load().g16_free(ptr)
+    return data
+
+
+# ------------------------------------------------------------------ snarkjs-shaped helpers
+def _dec(b):
+    return str(int.from_bytes(b, "little"))
+
+
+def proof_to_obj(pr):
+    """g16_proof -> the object snarkjs returns (decimal strings, key order of groth16_prove.js)."""
+    a, b, c = bytes(pr.a), bytes(pr.b), bytes(pr.c)
+
+    def g1(x):
+        return ["0", "1", "0"] if x == bytes(64) else [_dec(x[:32]), _dec(x[32:]), "1"]
+    if b == bytes(128):
+        pb = [["0", "0"], ["1", "0"], ["0", "0"]]
+    else:
+        pb = [[_dec(b[0:32]), _dec(b[32:64])], [_dec(b[64:96]), _dec(b[96:128])], ["1", "0"]]
+    return {"pi_a": g1(a), "pi_b": pb, "pi_c": g1(c), "protocol": "groth16", "curve": "bn128"}
+
+
+def stringify(obj):
+    """JSON.stringify(obj, null, 1), what the snarkjs CLI writes to proof.json / public.json."""
+    return json.dumps(obj, indent=1, separators=(",", ": "))
+
+
+class Prover:
+    """Resident proving key on one GPU (or one shard of it)."""
+
+    def __init__(self, zkey, device=0, shard_rank=0, shard_count=1, window_bits=0, task_len=0):
+        lib = load()
+        if isinstance(zkey, (str, os.PathLike)):
+            with open(zkey, "rb") as f:
+                zkey = f.read()
+        self._h = C.c_void_p()
+        opts = Opts(device, shard_rank, shard_count, window_bits, task_len, 0)
+        _check(lib.g16_create(zkey, len(zkey), C.byref(opts), C.byref(self._h)))
+        self.info = Info()
+        _check(lib.g16_get_info(self._h, C.byref(self.info)))
+
+    def close(self):
+        if getattr(self, "_h", None) and self._h.value:
+            load().g16_destroy(self._h)
+            self._h = C.c_void_p()
+
+    __del__ = close
+
+    def _pub(self):
+        return C.create_string_buffer(max(1, self.info.n_public * 32))
+
+    def _unpack(self, pr, pub):
+        p = self.info.n_public
+        return proof_to_obj(pr), [_dec(pub.raw[i * 32:(i + 1) * 32]) for i in range(p)]
+
+    def prove(self, wtns, r=None, s=None):
+        """snarkjs groth16.prove(zkey, wtns) -> (proof, publicSignals); r, s = 32-byte LE or None."""
+        if isinstance(wtns, (str, os.PathLike)):
+            with open(wtns, "rb") as f:
+                wtns = f.read()
+        pr, pub = Proof(), self._pub()
+        _check(load().g16_prove(self._h, wtns, len(wtns), r, s, C.byref(pr), pub))
+        return self._unpack(pr, pub)
+
+    def stage(self, slot, wtns):
+        _check(load().g16_stage_witness(self._h, slot, wtns, len(wtns)))
+
+    def prove_staged(self, slot, r=None, s=None):
+        pr, pub = Proof(), self._pub()
+        _check(load().g16_prove_staged(self._h, slot, r, s, C.byref(pr), pub))
+        return self._unpack(pr, pub)
+
+    def prove_staged_raw(self, slot, r, s, pr, pub):
+        """Timed path of bench.py: no Python-side formatting."""
+        return load().g16_prove_staged(self._h, slot, r, s, C.byref(pr), pub)
+
+    def prove_partial(self, slot):
+        buf = C.create_string_buffer(PARTIAL_BYTES)
+        _check(load().g16_prove_partial(self._h, slot, buf))
+        return buf.raw
+
+    def prove_finish(self, slot, partials, r=None, s=None):
+        pr, pub = Proof(), self._pub()
+        blob = b"".join(partials)
+        _check(load().g16_prove_finish(self._h, slot, blob, len(partials), r, s, C.byref(pr), pub))
+        return self._unpack(pr, pub)
+
+    def timings(self):
+        t = Timings()
+        _check(load().g16_get_timings(self._h, C.byref(t)))
+        return {"upload_ms": t.upload_ms, "qap_ms": t.qap_ms, "ntt_ms": t.ntt_ms,
+                "msm_ms": list(t.msm_ms), "tail_ms": t.tail_ms, "total_ms": t.total_ms,
+                "msm_accum_kernel_ms": list(t.msm_accum_kernel_ms)}
+
+
+# ------------------------------------------------------------------ operator-level (ffjavascript twins)
+def fr_fft(buf, inverse=False, device=0):
+    out = C.create_string_buffer(bytes(buf), len(buf))
+    fn = load().g16_fr_ifft if inverse else load().g16_fr_fft
+    _check(fn(device, out, len(buf) // 32))
+    return out.raw
+
+
+def field_op(field, op, a, b, device=0):
+    out = C.create_string_buffer(len(a))
+    _check(load().g16_field_op(device, field, op, a, b, out, len(a) // 32))
+    return out.raw
+
+
+def ec_add(curve, a, b, device=0):
+    psz = 128 if curve == 2 else 64
+    out = C.create_string_buffer(len(a))
+    _check(load().g16_ec_add(device, curve, a, b, out, len(a) // psz))
+    return out.raw
+
+
+def multiexp(curve, bases, scalars, window_bits=0, device=0):
+    psz = 128 if curve == 2 else 64
+    out = C.create_string_buffer(psz)
+    fn = load().g16_g2_multiexp if curve == 2 else load().g16_g1_multiexp
+    _check(fn(device, bases, scalars, len(scalars) // 32, window_bits, out))
+    return out.raw
+
+
+# ------------------------------------------------------------------ test-only setup tool
+def synth_setup(n_vars, n_public, n_constraints, seed, threads=0):
+    """-> (zkey bytes, wtns bytes, vkey bytes)  (host only, no GPU needed)."""
+    lib = load()
+    z, w, v = C.c_void_p(), C.c_void_p(), C.c_void_p()
+    zl, wl, vl = C.c_size_t(), C.c_size_t(), C.c_size_t()
+    _check(lib.g16_synth_setup(n_vars, n_public, n_constraints, seed, threads, C.byref(z), C.byref(zl),
+                               C.byref(w), C.byref(wl), C.byref(v), C.byref(vl)))
+    return _take(z, zl), _take(w, wl), _take(v, vl)
+
+
+def synth_witness(n_vars, n_public, n_constraints, seed, wseed):
+    lib = load()
+    w, wl = C.c_void_p(), C.c_size_t()
+    _check(lib.g16_synth_witness(n_vars, n_public, n_constraints, seed, wseed, C.byref(w), C.byref(wl)))
+    return _take(w, wl)

@@ -1,0 +1,92 @@
+// Internal interfaces between the translation units of libg16hip.so (not part of the C ABI).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+#include <string>
+#include <vector>
+
+#include "../../include/g16_prover.h"
+#include "ec.cuh"
+
+namespace g16 {
+
+// ---------------------------------------------------------------- errors (thread-local text)
+void set_error(const std::string& msg);
+const char* get_error();
+
+#define G16_HIP(expr)                                                                      \
+  do {                                                                                     \
+    hipError_t _e = (expr);                                                                \
+    if (_e != hipSuccess) {                                                                \
+      g16::set_error(std::string(#expr) + ": " + hipGetErrorString(_e));                   \
+      return G16_E_HIP;                                                                    \
+    }                                                                                      \
+  } while (0)
+
+
+// ---------------------------------------------------------------- NTT (ntt.hip)
+struct NttPass { int lo_bits, S, tb; };
+struct NttTables {
+  int L = -1;                // log2 N
+  int tile_log = 0;
+  Fr* tw_fwd = nullptr;      // w_N^i, i < N/2 (Montgomery)
+  Fr* tw_inv = nullptr;      // w_N^-i
+  Fr* coset = nullptr;       // coset[j] = N^-1 * w_2N^bitrev(j)  (position order after the DIF iNTT)
+  std::vector<NttPass> passes;  // DIT order; DIF runs them reversed
+};
+int ntt_tables_create(NttTables& t, int L, hipStream_t st);
+void ntt_tables_destroy(NttTables& t);
+// Batched in-place transforms over `nvec` vectors (device pointers in host array vecs).
+// dif_inverse: natural in -> bit-reversed out with w^-1 (no scaling);  dit_forward: bit-reversed
+// in -> natural out with w.
+int ntt_dif_inverse(const NttTables& t, Fr* const* vecs, int nvec, hipStream_t st);
+int ntt_dit_forward(const NttTables& t, Fr* const* vecs, int nvec, hipStream_t st);
+// x[j] *= coset[j]  (fused 1/N and w_2N^i shift in bit-reversed position order)
+int ntt_coset_scale(const NttTables& t, Fr* const* vecs, int nvec, hipStream_t st);
+// x[j] *= N^-1, then bit-reverse permutation out-of-place helpers for the operator-level API
+int ntt_scale_bitrev(const NttTables& t, const Fr* in, Fr* out, bool scale_ninv, hipStream_t st);
+// P[i] = fromMontgomery(a[i]*b[i] - c[i])   (qap_joinABC + batchFromMontgomery)
+int ntt_join_abc(const Fr* a, const Fr* b, const Fr* c, Fr* p_std, size_t n, hipStream_t st);
+
+// ---------------------------------------------------------------- QAP (qap.hip)
+struct QapCsr {
+  // CSR of zkey section 4 per matrix (0 = A, 1 = B): rows = domainSize
+  uint32_t* row_ptr[2] = {nullptr, nullptr};  // [N+1]
+  uint32_t* col[2] = {nullptr, nullptr};      // signal index per record
+  Fr* val[2] = {nullptr, nullptr};            // coef*R^2 as stored in the file
+  size_t nnz[2] = {0, 0};
+  uint32_t N = 0;
+};
+// a[c] = sum val*w[col] (Montgomery), b likewise, cc = a*b; w is the standard-form witness
+int qap_eval(const QapCsr& q, const Fr* w_std, Fr* a, Fr* b, Fr* cc, hipStream_t st);
+
+// ---------------------------------------------------------------- MSM (msm_g1.hip / msm_g2.hip)
+struct MsmConfig {
+  int c = 0;           // window bits (0 = choose from n)
+  int task_len = 0;    // max sorted entries per accumulation task (0 = default)
+};
+struct MsmWorkspace;   // opaque, msm.cuh
+// Fixed-base-set MSM instance: bases resident in HBM, infinity points compacted away.
+struct MsmInstance {
+  int curve = 1;               // 1 = G1, 2 = G2
+  uint32_t n = 0;              // non-infinity bases
+  void* d_bases = nullptr;     // Affine<F>[n] (Montgomery)
+  uint32_t* d_src = nullptr;   // scalar index of base i (into the scalar vector handed to run)
+  int c = 0, W = 0;
+  uint32_t nbuckets = 0;       // per window = 2^(c-1)
+  uint32_t task_len = 0;
+};
+size_t msm_point_bytes(int curve);   // XYZZ bytes: 128 (G1) / 256 (G2)
+// bases_host: n_total affine points in file layout; keeps only non-infinity ones.
+int msm_instance_create(MsmInstance& m, int curve, const uint8_t* bases_host, uint32_t n_total,
+                        uint32_t scalar_offset, const MsmConfig& cfg);
+void msm_instance_destroy(MsmInstance& m);
+int msm_workspace_create(MsmWorkspace** ws, const MsmInstance* insts, int ninst);
+void msm_workspace_destroy(MsmWorkspace* ws);
+// Runs the MSM of `m` against scalars d_scalars (standard form, 32 B each) and writes the W
+// per-window sums (XYZZ, Montgomery) to host memory out_windows (W * msm_point_bytes).
+int msm_run(const MsmInstance& m, MsmWorkspace* ws, const Fr* d_scalars, uint8_t* out_windows,
+            hipStream_t st);
+
+}  // namespace g16

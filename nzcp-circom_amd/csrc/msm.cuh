@@ -1,0 +1,326 @@
+// Pippenger multi-scalar multiplication on BN254 G1/G2.
+//
+// Replaces ffjavascript 0.2.48 engine_multiexp.js + wasmcurves 0.1.0 build_multiexp.js
+// (`G1/G2.multiExpAffine`, pins /root/reference/yarn.lock:408-416, 1132-1138): same inputs
+// (affine Montgomery bases in zkey-section byte layout, 32-byte standard-form scalars), same
+// group element out.  The reference chunks points across web-workers and runs an unsigned-window
+// bucket method per chunk; this is a different schedule for the same sum:
+//
+//   1. msm_count / msm_scatter: signed c-bit digits (carry-free: one 256-bit add of the constant
+//      K = sum 2^(c-1) 2^(cj) turns signed recoding into plain bit extraction), counting sort of
+//      (point, sign) by bucket key = window*2^(c-1) + |digit|-1.  Wave-ballot aggregation for
+//      the scalar value 1 (~30 % of an NZCP witness) so one hot counter does
+//      not serialise the atomics.
+//   2. msm_accumulate: buckets longer than task_len are split into tasks; one lane per task walks
+//      its slice of the sorted list, gathers the 64/128-byte affine point and mixed-adds it into
+//      an XYZZ accumulator held in VGPRs.
+//   3. msm_bucket_reduce: per window, sum k*S_k by running sums over segments of 16 buckets plus a
+//      short double-and-add for the segment offset.
+//   4. msm_wave_reduce: 64 -> 1 tree per wavefront with __shfl_down of the limbs.
+//   Window sums (W points) go back to the host, which does the c*W doublings (prover.cpp).
+//
+// Roofline note: ~10 Fq products per gathered 64-byte point, each ~130
+// v_mad_u64_u32: the kernel is integer-VALU bound by two orders of magnitude, HBM sees one
+// random 64 B read per add.
+#pragma once
+#include "internal.h"
+
+namespace g16 {
+
+struct MsmWorkspace {
+  uint32_t max_entries = 0, max_buckets = 0, max_tasks = 0, max_seg = 0;
+  uint32_t* d_cnt = nullptr;
+  uint32_t* d_off = nullptr;
+  uint32_t* d_cursor = nullptr;
+  uint32_t* d_toff = nullptr;
+  uint32_t* d_sorted = nullptr;
+  uint32_t* d_task_bucket = nullptr;
+  void* d_partial = nullptr;
+  void* d_seg = nullptr;
+  void* d_red = nullptr;
+  uint8_t* h_pinned = nullptr;
+};
+
+struct U256 { uint32_t v[8]; };
+
+static constexpr uint32_t kSegLen = 16;   // buckets per reduce segment
+
+__device__ __forceinline__ uint32_t msm_extract(const uint32_t s[8], int pos, int c) {
+  const int word = pos >> 5, off = pos & 31;
+  if (word >= 8) return 0;
+  uint64_t v = s[word];
+  if (word + 1 < 8) v |= (uint64_t)s[word + 1] << 32;
+  return (uint32_t)(v >> off) & ((1u << c) - 1);
+}
+
+// Loads scalar, adds K; returns true when the scalar is exactly 1.
+__device__ __forceinline__ bool msm_load_scalar(const Fr* __restrict__ scalars, const uint32_t* __restrict__ src,
+                                                uint32_t i, const U256& K, uint32_t s[8]) {
+  const Fr x = scalars[src ? src[i] : i];
+  uint32_t hi = 0;
+#pragma unroll
+  for (int k = 1; k < 8; k++) hi |= x.v[k];
+  const bool one = (hi == 0 && x.v[0] == 1);
+  uint64_t cy = 0;
+#pragma unroll
+  for (int k = 0; k < 8; k++) {
+    cy += (uint64_t)x.v[k] + K.v[k];
+    s[k] = (uint32_t)cy;
+    cy >>= 32;
+  }
+  return one;
+}
+
+// digit of window j -> key (or 0xffffffff when the digit is zero) and sign
+__device__ __forceinline__ uint32_t msm_key(const uint32_t s[8], int j, int c, int W, uint32_t B, uint32_t& neg) {
+  const uint32_t e = msm_extract(s, j * c, c);
+  int32_t d = (j == W - 1) ? (int32_t)e : (int32_t)e - (int32_t)B;
+  neg = d < 0 ? 1u : 0u;
+  const uint32_t mag = d < 0 ? (uint32_t)(-d) : (uint32_t)d;
+  return mag == 0 ? 0xffffffffu : (uint32_t)j * B + (mag - 1);
+}
+
+static __global__ __launch_bounds__(256) void msm_count_kernel(const Fr* __restrict__ scalars,
+                                                        const uint32_t* __restrict__ src, uint32_t n,
+                                                        int c, int W, U256 K, uint32_t* __restrict__ cnt) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  uint32_t s[8];
+  bool one = false;
+  const bool live = i < n;
+  if (live) one = msm_load_scalar(scalars, src, i, K, s);
+  const uint32_t B = 1u << (c - 1);
+  // value 1 -> key 0 (window 0, |digit| 1): aggregate across the wave
+  const unsigned long long m = __ballot(live && one);
+  if (m) {
+    const int lane = threadIdx.x & 63;
+    if (live && one && (m & ((1ull << lane) - 1)) == 0) atomicAdd(&cnt[0], (uint32_t)__popcll(m));
+  }
+  if (!live || one) return;
+  for (int j = 0; j < W; j++) {
+    uint32_t neg;
+    const uint32_t key = msm_key(s, j, c, W, B, neg);
+    if (key != 0xffffffffu) atomicAdd(&cnt[key], 1u);
+  }
+}
+
+static __global__ __launch_bounds__(256) void msm_scatter_kernel(const Fr* __restrict__ scalars,
+                                                          const uint32_t* __restrict__ src, uint32_t n,
+                                                          int c, int W, U256 K, uint32_t* __restrict__ cursor,
+                                                          uint32_t* __restrict__ sorted) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  uint32_t s[8];
+  bool one = false;
+  const bool live = i < n;
+  if (live) one = msm_load_scalar(scalars, src, i, K, s);
+  const uint32_t B = 1u << (c - 1);
+  const unsigned long long m = __ballot(live && one);
+  if (m) {
+    const int lane = threadIdx.x & 63;
+    const int leader = __ffsll((long long)m) - 1;
+    uint32_t base = 0;
+    if (lane == leader) base = atomicAdd(&cursor[0], (uint32_t)__popcll(m));
+    base = __shfl(base, leader, 64);
+    if (live && one) sorted[base + (uint32_t)__popcll(m & ((1ull << lane) - 1))] = i;
+  }
+  if (!live || one) return;
+  for (int j = 0; j < W; j++) {
+    uint32_t neg;
+    const uint32_t key = msm_key(s, j, c, W, B, neg);
+    if (key != 0xffffffffu) {
+      const uint32_t pos = atomicAdd(&cursor[key], 1u);
+      sorted[pos] = i | (neg << 31);
+    }
+  }
+}
+
+// Single-workgroup exclusive scans: off = scan(cnt), toff = scan(ceil(cnt/task_len)); cursor = off.
+static __global__ __launch_bounds__(1024) void msm_scan_kernel(const uint32_t* __restrict__ cnt, uint32_t nb,
+                                                        uint32_t task_len, uint32_t* __restrict__ off,
+                                                        uint32_t* __restrict__ cursor,
+                                                        uint32_t* __restrict__ toff) {
+  __shared__ uint32_t sh_a[1024], sh_b[1024];
+  const uint32_t tid = threadIdx.x;
+  const uint32_t chunk = (nb + 1023) / 1024;
+  const uint32_t lo = tid * chunk, hi = (lo + chunk < nb) ? lo + chunk : nb;
+  uint32_t sa = 0, sb = 0;
+  for (uint32_t k = lo; k < hi; k++) {
+    const uint32_t v = cnt[k];
+    sa += v;
+    sb += (v + task_len - 1) / task_len;
+  }
+  sh_a[tid] = sa;
+  sh_b[tid] = sb;
+  __syncthreads();
+  for (uint32_t d = 1; d < 1024; d <<= 1) {
+    uint32_t va = 0, vb = 0;
+    if (tid >= d) { va = sh_a[tid - d]; vb = sh_b[tid - d]; }
+    __syncthreads();
+    sh_a[tid] += va;
+    sh_b[tid] += vb;
+    __syncthreads();
+  }
+  uint32_t pa = sh_a[tid] - sa, pb = sh_b[tid] - sb;  // exclusive prefix of this chunk
+  for (uint32_t k = lo; k < hi; k++) {
+    const uint32_t v = cnt[k];
+    off[k] = pa;
+    cursor[k] = pa;
+    toff[k] = pb;
+    pa += v;
+    pb += (v + task_len - 1) / task_len;
+  }
+  if (tid == 1023) { off[nb] = sh_a[1023]; toff[nb] = sh_b[1023]; }
+}
+
+static __global__ __launch_bounds__(256) void msm_task_fill_kernel(const uint32_t* __restrict__ toff, uint32_t nb,
+                                                            uint32_t* __restrict__ task_bucket) {
+  const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= nb) return;
+  for (uint32_t t = toff[b], e = toff[b + 1]; t < e; t++) task_bucket[t] = b;
+}
+
+template <class F>
+__global__ __launch_bounds__(64) void msm_accumulate_kernel(const Affine<F>* __restrict__ bases,
+                                                            const uint32_t* __restrict__ sorted,
+                                                            const uint32_t* __restrict__ off,
+                                                            const uint32_t* __restrict__ toff, uint32_t nb,
+                                                            const uint32_t* __restrict__ task_bucket,
+                                                            uint32_t task_len, XYZZ<F>* __restrict__ partial) {
+  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= toff[nb]) return;
+  const uint32_t b = task_bucket[t];
+  const uint32_t k = t - toff[b];
+  const uint32_t cntb = off[b + 1] - off[b];
+  const uint32_t start = off[b] + k * task_len;
+  uint32_t len = cntb - k * task_len;
+  if (len > task_len) len = task_len;
+  XYZZ<F> acc;
+  xyzz_set_inf(acc);
+  for (uint32_t e = start; e < start + len; e++) {
+    const uint32_t idx = sorted[e];
+    Affine<F> p = bases[idx & 0x7fffffffu];
+    if (idx >> 31) p.y = F::neg(p.y);
+    xyzz_madd(acc, p);
+  }
+  partial[t] = acc;
+}
+
+template <class F>
+__device__ __forceinline__ void msm_mul_small(XYZZ<F>& r, const XYZZ<F>& p, uint32_t k) {
+  xyzz_set_inf(r);
+  if (k == 0) return;
+  for (int i = 31 - __clz(k); i >= 0; i--) {
+    xyzz_dbl(r);
+    if ((k >> i) & 1) xyzz_add(r, p);
+  }
+}
+
+// seg[j*nseg + g] = sum_{bi in segment g of window j} (bi+1) * S_bi
+template <class F>
+__global__ __launch_bounds__(64) void msm_bucket_reduce_kernel(const XYZZ<F>* __restrict__ partial,
+                                                               const uint32_t* __restrict__ toff, uint32_t B,
+                                                               uint32_t nseg, uint32_t W,
+                                                               XYZZ<F>* __restrict__ seg) {
+  const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
+  if (tid >= W * nseg) return;
+  const uint32_t j = tid / nseg, g = tid % nseg;
+  const uint32_t lo = g * kSegLen;
+  const uint32_t hi = (lo + kSegLen < B) ? lo + kSegLen : B;
+  XYZZ<F> run, acc;
+  xyzz_set_inf(run);
+  xyzz_set_inf(acc);
+  for (uint32_t bi = hi; bi-- > lo;) {
+    const uint32_t b = j * B + bi;
+    for (uint32_t t = toff[b], e = toff[b + 1]; t < e; t++) {
+      const XYZZ<F> s = partial[t];
+      xyzz_add(run, s);
+    }
+    xyzz_add(acc, run);
+  }
+  if (lo != 0) {
+    XYZZ<F> m;
+    msm_mul_small(m, run, lo);
+    xyzz_add(acc, m);
+  }
+  seg[tid] = acc;
+}
+
+template <class F> __device__ __forceinline__ XYZZ<F> xyzz_shfl_down(const XYZZ<F>& p, int delta) {
+  XYZZ<F> r;
+  constexpr int NW = sizeof(XYZZ<F>) / 4;
+  const uint32_t* s = reinterpret_cast<const uint32_t*>(&p);
+  uint32_t* d = reinterpret_cast<uint32_t*>(&r);
+#pragma unroll
+  for (int i = 0; i < NW; i++) d[i] = __shfl_down(s[i], delta, 64);
+  return r;
+}
+
+// out[j*nout + blk] = sum of in[j*nin + blk*64 .. +64)
+template <class F>
+__global__ __launch_bounds__(64) void msm_wave_reduce_kernel(const XYZZ<F>* __restrict__ in, uint32_t nin,
+                                                             XYZZ<F>* __restrict__ out, uint32_t nout) {
+  const uint32_t j = blockIdx.y, blk = blockIdx.x, lane = threadIdx.x;
+  const uint32_t i = blk * 64 + lane;
+  XYZZ<F> p;
+  if (i < nin) p = in[(size_t)j * nin + i];
+  else xyzz_set_inf(p);
+  for (int d = 32; d >= 1; d >>= 1) {
+    const XYZZ<F> q = xyzz_shfl_down(p, d);
+    xyzz_add(p, q);
+  }
+  if (lane == 0) out[(size_t)j * nout + blk] = p;
+}
+
+// ------------------------------------------------------------------ host side (per curve)
+inline void msm_make_K(int c, int W, U256& K) {
+  for (int i = 0; i < 8; i++) K.v[i] = 0;
+  for (int j = 0; j + 1 < W; j++) {
+    const int bit = c * j + c - 1;
+    if (bit < 256) K.v[bit >> 5] |= 1u << (bit & 31);
+  }
+}
+
+template <class F>
+int msm_run_t(const MsmInstance& m, MsmWorkspace* ws, const Fr* d_scalars, uint8_t* out_windows,
+              hipStream_t st) {
+  using PT = XYZZ<F>;
+  const uint32_t W = (uint32_t)m.W, B = m.nbuckets, nb = W * B;
+  if (m.n == 0) {
+    memset(out_windows, 0, (size_t)W * sizeof(PT));
+    return G16_OK;
+  }
+  const uint32_t nseg = (B + kSegLen - 1) / kSegLen;
+  U256 K;
+  msm_make_K(m.c, m.W, K);
+  G16_HIP(hipMemsetAsync(ws->d_cnt, 0, (size_t)(nb + 1) * 4, st));
+  const uint32_t nblk = (m.n + 255) / 256;
+  msm_count_kernel<<<nblk, 256, 0, st>>>(d_scalars, m.d_src, m.n, m.c, m.W, K, ws->d_cnt);
+  msm_scan_kernel<<<1, 1024, 0, st>>>(ws->d_cnt, nb, m.task_len, ws->d_off, ws->d_cursor, ws->d_toff);
+  msm_scatter_kernel<<<nblk, 256, 0, st>>>(d_scalars, m.d_src, m.n, m.c, m.W, K, ws->d_cursor, ws->d_sorted);
+  msm_task_fill_kernel<<<(nb + 255) / 256, 256, 0, st>>>(ws->d_toff, nb, ws->d_task_bucket);
+  // upper bound on tasks: every non-empty bucket has <= 1 short task + entries/task_len full ones
+  const uint64_t max_tasks = (uint64_t)nb + ((uint64_t)m.n * W) / m.task_len;
+  msm_accumulate_kernel<F><<<(unsigned)((max_tasks + 63) / 64), 64, 0, st>>>(
+      (const Affine<F>*)m.d_bases, ws->d_sorted, ws->d_off, ws->d_toff, nb, ws->d_task_bucket, m.task_len,
+      (PT*)ws->d_partial);
+  msm_bucket_reduce_kernel<F><<<(W * nseg + 63) / 64, 64, 0, st>>>((const PT*)ws->d_partial, ws->d_toff, B,
+                                                                   nseg, W, (PT*)ws->d_seg);
+  // tree: d_seg (nseg per window) -> ... -> 1 per window, ping-pong between d_red halves
+  PT* cur = (PT*)ws->d_seg;
+  uint32_t cnt = nseg;
+  PT* bufs[2] = {(PT*)ws->d_red, (PT*)ws->d_red + (size_t)W * ((nseg + 63) / 64)};
+  int flip = 0;
+  while (cnt > 1) {
+    const uint32_t nout = (cnt + 63) / 64;
+    msm_wave_reduce_kernel<F><<<dim3(nout, W), 64, 0, st>>>(cur, cnt, bufs[flip], nout);
+    cur = bufs[flip];
+    flip ^= 1;
+    cnt = nout;
+  }
+  G16_HIP(hipGetLastError());
+  G16_HIP(hipMemcpyAsync(ws->h_pinned, cur, (size_t)W * sizeof(PT), hipMemcpyDeviceToHost, st));
+  G16_HIP(hipStreamSynchronize(st));
+  memcpy(out_windows, ws->h_pinned, (size_t)W * sizeof(PT));
+  return G16_OK;
+}
+
+}  // namespace g16

@@ -1,0 +1,117 @@
+// G1 instantiation of the MSM kernels + the curve-independent host plumbing (instances, workspace).
+#include <string.h>
+
+#include "msm.cuh"
+
+namespace g16 {
+
+size_t msm_point_bytes(int curve) { return curve == 2 ? sizeof(G2XYZZ) : sizeof(G1XYZZ); }
+
+static int choose_c(uint32_t n) {
+  // minimise W * (n + 2.5 * 2^(c-1)) over c in [4, 16], W = ceil(256 / c)
+  int best = 4;
+  double best_cost = 1e300;
+  for (int c = 4; c <= 16; c++) {
+    const int W = (256 + c - 1) / c;
+    const double cost = (double)W * ((double)n + 2.5 * (double)(1u << (c - 1)));
+    if (cost < best_cost) { best_cost = cost; best = c; }
+  }
+  return best;
+}
+
+int msm_instance_create(MsmInstance& m, int curve, const uint8_t* bases_host, uint32_t n_total,
+                        uint32_t scalar_offset, const MsmConfig& cfg) {
+  const size_t psz = curve == 2 ? sizeof(G2Affine) : sizeof(G1Affine);
+  m.curve = curve;
+  std::vector<uint32_t> src;
+  std::vector<uint8_t> packed;
+  src.reserve(n_total);
+  packed.reserve((size_t)n_total * psz);
+  for (uint32_t i = 0; i < n_total; i++) {
+    const uint8_t* p = bases_host + (size_t)i * psz;
+    bool inf = true;
+    for (size_t k = 0; k < psz; k += 8) {
+      uint64_t w;
+      memcpy(&w, p + k, 8);
+      if (w) { inf = false; break; }
+    }
+    if (inf) continue;
+    src.push_back(scalar_offset + i);
+    packed.insert(packed.end(), p, p + psz);
+  }
+  m.n = (uint32_t)src.size();
+  if (m.n >= 0x7fffffffu) { set_error("msm: too many bases"); return G16_E_ARG; }
+  m.c = cfg.c ? cfg.c : choose_c(m.n ? m.n : 1);
+  if (m.c < 2 || m.c > 16) { set_error("msm: window bits must be in [2,16]"); return G16_E_ARG; }
+  m.W = (256 + m.c - 1) / m.c;
+  m.nbuckets = 1u << (m.c - 1);
+  m.task_len = cfg.task_len ? (uint32_t)cfg.task_len : 256u;
+  if (m.n) {
+    G16_HIP(hipMalloc(&m.d_bases, packed.size()));
+    G16_HIP(hipMalloc(&m.d_src, (size_t)m.n * 4));
+    G16_HIP(hipMemcpy(m.d_bases, packed.data(), packed.size(), hipMemcpyHostToDevice));
+    G16_HIP(hipMemcpy(m.d_src, src.data(), (size_t)m.n * 4, hipMemcpyHostToDevice));
+  }
+  return G16_OK;
+}
+
+void msm_instance_destroy(MsmInstance& m) {
+  if (m.d_bases) (void)hipFree(m.d_bases);
+  if (m.d_src) (void)hipFree(m.d_src);
+  m.d_bases = nullptr;
+  m.d_src = nullptr;
+  m.n = 0;
+}
+
+int msm_workspace_create(MsmWorkspace** out, const MsmInstance* insts, int ninst) {
+  MsmWorkspace* ws = new MsmWorkspace();
+  size_t part_bytes = 0, seg_bytes = 0, red_bytes = 0, pin_bytes = 0;
+  for (int i = 0; i < ninst; i++) {
+    const MsmInstance& m = insts[i];
+    const uint64_t nb = (uint64_t)m.W * m.nbuckets;
+    const uint64_t entries = (uint64_t)m.n * m.W;
+    const uint64_t tasks = nb + entries / m.task_len + 64;
+    const uint64_t nseg = (m.nbuckets + kSegLen - 1) / kSegLen;
+    const size_t pb = msm_point_bytes(m.curve);
+    if (entries > ws->max_entries) ws->max_entries = (uint32_t)entries;
+    if (nb > ws->max_buckets) ws->max_buckets = (uint32_t)nb;
+    if (tasks > ws->max_tasks) ws->max_tasks = (uint32_t)tasks;
+    if (tasks * pb > part_bytes) part_bytes = tasks * pb;
+    if (m.W * nseg * pb > seg_bytes) seg_bytes = m.W * nseg * pb;
+    const size_t rb = 2 * (size_t)m.W * ((nseg + 63) / 64) * pb;
+    if (rb > red_bytes) red_bytes = rb;
+    if ((size_t)m.W * pb > pin_bytes) pin_bytes = (size_t)m.W * pb;
+  }
+  *out = ws;
+  G16_HIP(hipMalloc(&ws->d_cnt, ((size_t)ws->max_buckets + 1) * 4));
+  G16_HIP(hipMalloc(&ws->d_off, ((size_t)ws->max_buckets + 1) * 4));
+  G16_HIP(hipMalloc(&ws->d_cursor, ((size_t)ws->max_buckets + 1) * 4));
+  G16_HIP(hipMalloc(&ws->d_toff, ((size_t)ws->max_buckets + 1) * 4));
+  G16_HIP(hipMalloc(&ws->d_sorted, ((size_t)ws->max_entries + 1) * 4));
+  G16_HIP(hipMalloc(&ws->d_task_bucket, ((size_t)ws->max_tasks + 1) * 4));
+  G16_HIP(hipMalloc(&ws->d_partial, part_bytes + 256));
+  G16_HIP(hipMalloc(&ws->d_seg, seg_bytes + 256));
+  G16_HIP(hipMalloc(&ws->d_red, red_bytes + 256));
+  G16_HIP(hipHostMalloc((void**)&ws->h_pinned, pin_bytes + 256));
+  return G16_OK;
+}
+
+void msm_workspace_destroy(MsmWorkspace* ws) {
+  if (!ws) return;
+  void* ptrs[] = {ws->d_cnt, ws->d_off, ws->d_cursor, ws->d_toff, ws->d_sorted, ws->d_task_bucket,
+                  ws->d_partial, ws->d_seg, ws->d_red};
+  for (void* p : ptrs)
+    if (p) (void)hipFree(p);
+  if (ws->h_pinned) (void)hipHostFree(ws->h_pinned);
+  delete ws;
+}
+
+int msm_run_g2(const MsmInstance& m, MsmWorkspace* ws, const Fr* d_scalars, uint8_t* out, hipStream_t st);
+
+int msm_run(const MsmInstance& m, MsmWorkspace* ws, const Fr* d_scalars, uint8_t* out_windows,
+            hipStream_t st) {
+  if (m.curve == 2) return msm_run_g2(m, ws, d_scalars, out_windows, st);
+  return msm_run_t<FqOps>(m, ws, d_scalars, out_windows, st);
+}
+
+}  // namespace g16

@@ -1,0 +1,533 @@
+// Host side of libg16hip.so: snarkjs container parsing, device orchestration, proof tail, C ABI.
+//
+// Mirrors snarkjs 0.4.12 `groth16.prove` (groth16_prove.js; pin /root/reference/yarn.lock:987-1001;
+// call stack SURVEY.md section 3.3): the same checks in the same order with the same Error texts,
+// the same five multi-exponentiations and the same blinding equations.
+// There is NO CPU fallback: without a HIP device every compute entry point fails with G16_E_NOGPU.
+#include <fcntl.h>
+#include <string.h>
+#include <unistd.h>
+
+#include <map>
+#include <memory>
+#include <mutex>
+
+#include "../../include/g16_prover.h"
+#include "internal.h"
+
+namespace g16 {
+
+// ------------------------------------------------------------------ errors
+static thread_local std::string g_err;
+void set_error(const std::string& msg) { g_err = msg; }
+const char* get_error() { return g_err.c_str(); }
+
+// ------------------------------------------------------------------ binfile (App. A.1)
+struct Section { const uint8_t* p = nullptr; uint64_t size = 0; bool present = false; };
+struct BinFile { std::map<uint32_t, Section> secs; uint32_t version = 0; };
+
+static uint32_t rd32(const uint8_t* p) { uint32_t v; memcpy(&v, p, 4); return v; }
+static uint64_t rd64(const uint8_t* p) { uint64_t v; memcpy(&v, p, 8); return v; }
+
+// @iden3/binfileutils readBinFile(fileName, type, maxVersion) [EXT]
+static int read_binfile(const uint8_t* buf, size_t len, const char* magic, uint32_t max_version,
+                        const char* name, BinFile& out) {
+  if (!buf || len < 12 || memcmp(buf, magic, 4) != 0) {
+    set_error(std::string(name) + ": Invalid File format");
+    return G16_E_FORMAT;
+  }
+  out.version = rd32(buf + 4);
+  if (out.version > max_version) { set_error("Version not supported"); return G16_E_FORMAT; }
+  const uint32_t nsec = rd32(buf + 8);
+  size_t pos = 12;
+  for (uint32_t i = 0; i < nsec; i++) {
+    if (pos + 12 > len) { set_error(std::string(name) + ": Invalid File format"); return G16_E_FORMAT; }
+    const uint32_t id = rd32(buf + pos);
+    const uint64_t sz = rd64(buf + pos + 4);
+    pos += 12;
+    if (sz > len - pos) { set_error(std::string(name) + ": Invalid File format"); return G16_E_FORMAT; }
+    Section& s = out.secs[id];
+    if (!s.present) { s.p = buf + pos; s.size = sz; s.present = true; }
+    pos += sz;
+  }
+  return G16_OK;
+}
+static int need_section(const BinFile& f, uint32_t id, const char* name, Section& out) {
+  auto it = f.secs.find(id);
+  if (it == f.secs.end()) {
+    set_error(std::string(name) + ": Missing section " + std::to_string(id));
+    return G16_E_FORMAT;
+  }
+  out = it->second;
+  return G16_OK;
+}
+
+static const uint32_t kQ[8] = G16_FQ_P;
+static const uint32_t kR[8] = G16_FR_P;
+
+// ------------------------------------------------------------------ host point helpers
+template <class F> static void horner_windows(XYZZ<F>& total, const uint8_t* windows, int W, int c) {
+  xyzz_set_inf(total);
+  for (int j = W - 1; j >= 0; j--) {
+    if (!xyzz_is_inf(total))
+      for (int k = 0; k < c; k++) xyzz_dbl(total);
+    XYZZ<F> w;
+    memcpy(&w, windows + (size_t)j * sizeof(XYZZ<F>), sizeof(w));
+    xyzz_add(total, w);
+  }
+}
+static void g1_out(uint8_t out[64], const G1Affine& p) {  // Montgomery affine -> standard LE bytes
+  Fq x = fp_from_mont(p.x), y = fp_from_mont(p.y);
+  memcpy(out, x.v, 32);
+  memcpy(out + 32, y.v, 32);
+}
+static void g2_out(uint8_t out[128], const G2Affine& p) {
+  Fq v[4] = {fp_from_mont(p.x.a), fp_from_mont(p.x.b), fp_from_mont(p.y.a), fp_from_mont(p.y.b)};
+  for (int i = 0; i < 4; i++) memcpy(out + 32 * i, v[i].v, 32);
+}
+static bool scalar_lt_r(const uint32_t s[8]) {
+  for (int i = 7; i >= 0; i--) {
+    if (s[i] < kR[i]) return true;
+    if (s[i] > kR[i]) return false;
+  }
+  return false;
+}
+static int random_scalar(uint32_t out[8]) {  // snarkjs Fr.random() counterpart: uniform in [0, r)
+  int fd = open("/dev/urandom", O_RDONLY);
+  if (fd < 0) { set_error("cannot open /dev/urandom"); return G16_E_STATE; }
+  for (;;) {
+    if (read(fd, out, 32) != 32) { close(fd); set_error("short read from /dev/urandom"); return G16_E_STATE; }
+    out[7] &= 0x3fffffffu;  // r < 2^254
+    if (scalar_lt_r(out)) break;
+  }
+  close(fd);
+  return G16_OK;
+}
+
+struct Partial {  // XYZZ sums of one shard, Montgomery
+  G1XYZZ A, B1, C, H;
+  G2XYZZ B2;
+};
+static_assert(sizeof(Partial) == G16_PARTIAL_BYTES, "partial blob layout");
+
+}  // namespace g16
+
+using namespace g16;
+
+// ====================================================================== the prover handle
+struct g16_prover {
+  int device = 0;
+  int shard_rank = 0, shard_count = 1;
+  hipStream_t st = nullptr;
+  uint32_t nVars = 0, nPublic = 0, N = 0, nCoefs = 0;
+  int L = 0;
+  G1Affine alpha1, beta1, delta1;
+  G2Affine beta2, delta2;
+  QapCsr csr;
+  NttTables ntt;
+  MsmInstance msm[5];  // A, B1, B2, C, H
+  MsmWorkspace* ws = nullptr;
+  Fr *d_a = nullptr, *d_b = nullptr, *d_c = nullptr, *d_p = nullptr;
+  std::vector<Fr*> slot_dev;
+  std::vector<std::vector<uint8_t>> slot_pub;
+  std::vector<uint8_t> winbuf;
+  g16_timings tm{};
+  hipEvent_t ev[8] = {};
+  std::mutex mu;
+
+  ~g16_prover() {
+    (void)hipSetDevice(device);
+    for (Fr* p : slot_dev) if (p) (void)hipFree(p);
+    Fr* vs[] = {d_a, d_b, d_c, d_p};
+    for (Fr* p : vs) if (p) (void)hipFree(p);
+    for (int m = 0; m < 2; m++) {
+      if (csr.row_ptr[m]) (void)hipFree(csr.row_ptr[m]);
+      if (csr.col[m]) (void)hipFree(csr.col[m]);
+      if (csr.val[m]) (void)hipFree(csr.val[m]);
+    }
+    ntt_tables_destroy(ntt);
+    for (auto& m : msm) msm_instance_destroy(m);
+    msm_workspace_destroy(ws);
+    for (auto& e : ev) if (e) (void)hipEventDestroy(e);
+    if (st) (void)hipStreamDestroy(st);
+  }
+};
+
+static int check_device(int device) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) {
+    set_error("no HIP device available: libg16hip has no CPU fallback");
+    return G16_E_NOGPU;
+  }
+  if (device < 0 || device >= n) { set_error("device ordinal out of range"); return G16_E_ARG; }
+  G16_HIP(hipSetDevice(device));
+  return G16_OK;
+}
+
+static void shard_range(uint32_t total, int rank, int count, uint32_t& lo, uint32_t& hi) {
+  lo = (uint32_t)((uint64_t)total * rank / count);
+  hi = (uint32_t)((uint64_t)total * (rank + 1) / count);
+}
+
+static int build_csr(g16_prover* P, const Section& s4) {
+  if (s4.size < 4) { set_error("zkey: Invalid File format"); return G16_E_FORMAT; }
+  const uint32_t nc = rd32(s4.p);
+  if ((uint64_t)nc * 44 + 4 > s4.size) { set_error("zkey: Invalid File format"); return G16_E_FORMAT; }
+  P->nCoefs = nc;
+  const uint32_t N = P->N;
+  std::vector<uint32_t> rp[2];
+  rp[0].assign((size_t)N + 1, 0);
+  rp[1].assign((size_t)N + 1, 0);
+  for (uint32_t i = 0; i < nc; i++) {
+    const uint8_t* rec = s4.p + 4 + (size_t)i * 44;
+    const uint32_t m = rd32(rec), c = rd32(rec + 4), s = rd32(rec + 8);
+    if (m > 1 || c >= N || s >= P->nVars) { set_error("zkey: coefficient record out of range"); return G16_E_FORMAT; }
+    rp[m][c + 1]++;
+  }
+  for (int m = 0; m < 2; m++)
+    for (uint32_t c = 0; c < N; c++) rp[m][c + 1] += rp[m][c];
+  std::vector<uint32_t> col[2];
+  std::vector<Fr> val[2];
+  std::vector<uint32_t> cur[2];
+  for (int m = 0; m < 2; m++) {
+    col[m].resize(rp[m][N]);
+    val[m].resize(rp[m][N]);
+    cur[m].assign(rp[m].begin(), rp[m].end() - 1);
+  }
+  for (uint32_t i = 0; i < nc; i++) {
+    const uint8_t* rec = s4.p + 4 + (size_t)i * 44;
+    const uint32_t m = rd32(rec), c = rd32(rec + 4), s = rd32(rec + 8);
+    const uint32_t k = cur[m][c]++;
+    col[m][k] = s;
+    memcpy(val[m][k].v, rec + 12, 32);
+  }
+  P->csr.N = N;
+  for (int m = 0; m < 2; m++) {
+    const size_t nnz = col[m].size();
+    P->csr.nnz[m] = nnz;
+    G16_HIP(hipMalloc(&P->csr.row_ptr[m], ((size_t)N + 1) * 4));
+    G16_HIP(hipMalloc(&P->csr.col[m], (nnz + 1) * 4));
+    G16_HIP(hipMalloc(&P->csr.val[m], (nnz + 1) * sizeof(Fr)));
+    G16_HIP(hipMemcpy(P->csr.row_ptr[m], rp[m].data(), ((size_t)N + 1) * 4, hipMemcpyHostToDevice));
+    if (nnz) {
+      G16_HIP(hipMemcpy(P->csr.col[m], col[m].data(), nnz * 4, hipMemcpyHostToDevice));
+      G16_HIP(hipMemcpy(P->csr.val[m], val[m].data(), nnz * sizeof(Fr), hipMemcpyHostToDevice));
+    }
+  }
+  return G16_OK;
+}
+
+static int create_impl(const uint8_t* zkey, size_t len, const g16_opts* opts, g16_prover* P) {
+  BinFile f;
+  int rc = read_binfile(zkey, len, "zkey", 2, "zkey", f);
+  if (rc) return rc;
+  Section s1, s2, s4, sb[5];
+  if ((rc = need_section(f, 1, "zkey", s1))) return rc;
+  if (s1.size < 4 || rd32(s1.p) != 1) { set_error("zkey file is not groth16"); return G16_E_FORMAT; }
+  if ((rc = need_section(f, 2, "zkey", s2))) return rc;
+  // zkey_utils.readHeaderGroth16 [EXT]
+  const size_t hdr = 4 + 32 + 4 + 32 + 12 + 64 + 64 + 128 + 128 + 64 + 128;
+  if (s2.size < hdr || rd32(s2.p) != 32 || rd32(s2.p + 36) != 32) {
+    set_error("zkey: Invalid File format");
+    return G16_E_FORMAT;
+  }
+  if (memcmp(s2.p + 4, kQ, 32) != 0 || memcmp(s2.p + 40, kR, 32) != 0) {
+    set_error("Curve not supported: zkey is not over bn128");
+    return G16_E_FORMAT;
+  }
+  const uint8_t* h = s2.p + 72;
+  P->nVars = rd32(h);
+  P->nPublic = rd32(h + 4);
+  P->N = rd32(h + 8);
+  h += 12;
+  if (P->N == 0 || (P->N & (P->N - 1)) || P->nPublic + 1 > P->nVars) {
+    set_error("zkey: Invalid File format");
+    return G16_E_FORMAT;
+  }
+  P->L = 0;
+  while ((1u << P->L) < P->N) P->L++;
+  memcpy(&P->alpha1, h, 64); h += 64;
+  memcpy(&P->beta1, h, 64); h += 64;
+  memcpy(&P->beta2, h, 128); h += 128;
+  h += 128;  // gamma2 (verifier only)
+  memcpy(&P->delta1, h, 64); h += 64;
+  memcpy(&P->delta2, h, 128);
+  if ((rc = need_section(f, 4, "zkey", s4))) return rc;
+  static const uint32_t ids[5] = {5, 6, 7, 8, 9};
+  for (int i = 0; i < 5; i++)
+    if ((rc = need_section(f, ids[i], "zkey", sb[i]))) return rc;
+  const uint32_t nC = P->nVars - P->nPublic - 1;
+  const uint64_t expect[5] = {(uint64_t)P->nVars * 64, (uint64_t)P->nVars * 64, (uint64_t)P->nVars * 128,
+                              (uint64_t)nC * 64, (uint64_t)P->N * 64};
+  for (int i = 0; i < 5; i++)
+    if (sb[i].size != expect[i]) { set_error("zkey: Invalid File format"); return G16_E_FORMAT; }
+
+  // ---- device side
+  P->device = opts ? opts->device : 0;
+  P->shard_count = (opts && opts->shard_count > 1) ? opts->shard_count : 1;
+  P->shard_rank = opts ? opts->shard_rank : 0;
+  if (P->shard_rank < 0 || P->shard_rank >= P->shard_count) { set_error("shard_rank out of range"); return G16_E_ARG; }
+  if ((rc = check_device(P->device))) return rc;
+  G16_HIP(hipStreamCreate(&P->st));
+  for (auto& e : P->ev) G16_HIP(hipEventCreate(&e));
+  if ((rc = build_csr(P, s4))) return rc;
+  if ((rc = ntt_tables_create(P->ntt, P->L, P->st))) return rc;
+  MsmConfig cfg;
+  cfg.c = opts ? opts->window_bits : 0;
+  cfg.task_len = opts ? opts->task_len : 0;
+  const uint32_t totals[5] = {P->nVars, P->nVars, P->nVars, nC, P->N};
+  const uint32_t base_off[5] = {0, 0, 0, P->nPublic + 1, 0};
+  const int curve[5] = {1, 1, 2, 1, 1};
+  for (int i = 0; i < 5; i++) {
+    uint32_t lo, hi;
+    shard_range(totals[i], P->shard_rank, P->shard_count, lo, hi);
+    const size_t psz = curve[i] == 2 ? 128 : 64;
+    if ((rc = msm_instance_create(P->msm[i], curve[i], sb[i].p + (size_t)lo * psz, hi - lo, base_off[i] + lo, cfg)))
+      return rc;
+  }
+  if ((rc = msm_workspace_create(&P->ws, P->msm, 5))) return rc;
+  const size_t vb = (size_t)P->N * sizeof(Fr);
+  G16_HIP(hipMalloc(&P->d_a, vb));
+  G16_HIP(hipMalloc(&P->d_b, vb));
+  G16_HIP(hipMalloc(&P->d_c, vb));
+  G16_HIP(hipMalloc(&P->d_p, vb));
+  size_t wb = 0;
+  for (auto& m : P->msm) {
+    const size_t b = (size_t)m.W * msm_point_bytes(m.curve);
+    if (b > wb) wb = b;
+  }
+  P->winbuf.resize(wb);
+  G16_HIP(hipStreamSynchronize(P->st));
+  return G16_OK;
+}
+
+// wtns_utils.readHeader + the checks of groth16.prove [EXT]
+static int parse_wtns(const g16_prover* P, const uint8_t* wtns, size_t len, const uint8_t** body) {
+  BinFile f;
+  int rc = read_binfile(wtns, len, "wtns", 2, "wtns", f);
+  if (rc) return rc;
+  Section s1, s2;
+  if ((rc = need_section(f, 1, "wtns", s1))) return rc;
+  if (s1.size < 8) { set_error("wtns: Invalid File format"); return G16_E_FORMAT; }
+  const uint32_t n8 = rd32(s1.p);
+  if (s1.size < 8 + (uint64_t)n8) { set_error("wtns: Invalid File format"); return G16_E_FORMAT; }
+  if (n8 != 32 || memcmp(s1.p + 4, kR, 32) != 0) {
+    set_error("Curve of the witness does not match the curve of the proving key");
+    return G16_E_FORMAT;
+  }
+  const uint32_t nw = rd32(s1.p + 4 + n8);
+  if (nw != P->nVars) {
+    set_error("Invalid witness length. Circuit: " + std::to_string(P->nVars) + ", witness: " + std::to_string(nw));
+    return G16_E_FORMAT;
+  }
+  if ((rc = need_section(f, 2, "wtns", s2))) return rc;
+  if (s2.size != (uint64_t)nw * 32) { set_error("wtns: Invalid File format"); return G16_E_FORMAT; }
+  *body = s2.p;
+  return G16_OK;
+}
+
+static int stage_impl(g16_prover* P, uint32_t slot, const uint8_t* wtns, size_t len) {
+  const uint8_t* body = nullptr;
+  int rc = parse_wtns(P, wtns, len, &body);
+  if (rc) return rc;
+  if (slot >= 65536) { set_error("slot out of range"); return G16_E_ARG; }
+  G16_HIP(hipSetDevice(P->device));
+  if (P->slot_dev.size() <= slot) { P->slot_dev.resize(slot + 1, nullptr); P->slot_pub.resize(slot + 1); }
+  if (!P->slot_dev[slot]) G16_HIP(hipMalloc(&P->slot_dev[slot], (size_t)P->nVars * sizeof(Fr)));
+  G16_HIP(hipEventRecord(P->ev[0], P->st));
+  G16_HIP(hipMemcpyAsync(P->slot_dev[slot], body, (size_t)P->nVars * 32, hipMemcpyHostToDevice, P->st));
+  G16_HIP(hipEventRecord(P->ev[1], P->st));
+  G16_HIP(hipStreamSynchronize(P->st));
+  (void)hipEventElapsedTime(&P->tm.upload_ms, P->ev[0], P->ev[1]);
+  P->slot_pub[slot].assign(body + 32, body + 32 + (size_t)P->nPublic * 32);
+  return G16_OK;
+}
+
+template <class F>
+static int run_one_msm(g16_prover* P, int i, const Fr* scalars, XYZZ<F>& out) {
+  hipEvent_t e0 = P->ev[6], e1 = P->ev[7];
+  G16_HIP(hipEventRecord(e0, P->st));
+  int rc = msm_run(P->msm[i], P->ws, scalars, P->winbuf.data(), P->st);
+  if (rc) return rc;
+  G16_HIP(hipEventRecord(e1, P->st));
+  G16_HIP(hipEventSynchronize(e1));
+  (void)hipEventElapsedTime(&P->tm.msm_ms[i], e0, e1);
+  horner_windows<F>(out, P->winbuf.data(), P->msm[i].W, P->msm[i].c);
+  return G16_OK;
+}
+
+// The device pipeline of one proof on a staged witness: QAP -> NTTs -> join -> 5 MSMs.
+static int device_impl(g16_prover* P, uint32_t slot, Partial& out) {
+  if (slot >= P->slot_dev.size() || !P->slot_dev[slot]) { set_error("witness slot not staged"); return G16_E_STATE; }
+  G16_HIP(hipSetDevice(P->device));
+  const Fr* d_w = P->slot_dev[slot];
+  int rc;
+  G16_HIP(hipEventRecord(P->ev[2], P->st));
+  if ((rc = qap_eval(P->csr, d_w, P->d_a, P->d_b, P->d_c, P->st))) return rc;
+  G16_HIP(hipEventRecord(P->ev[3], P->st));
+  Fr* vecs[3] = {P->d_a, P->d_b, P->d_c};
+  if ((rc = ntt_dif_inverse(P->ntt, vecs, 3, P->st))) return rc;
+  if ((rc = ntt_coset_scale(P->ntt, vecs, 3, P->st))) return rc;
+  if ((rc = ntt_dit_forward(P->ntt, vecs, 3, P->st))) return rc;
+  if ((rc = ntt_join_abc(P->d_a, P->d_b, P->d_c, P->d_p, P->N, P->st))) return rc;
+  G16_HIP(hipEventRecord(P->ev[4], P->st));
+  if ((rc = run_one_msm<FqOps>(P, 0, d_w, out.A))) return rc;
+  if ((rc = run_one_msm<FqOps>(P, 1, d_w, out.B1))) return rc;
+  if ((rc = run_one_msm<Fq2Ops>(P, 2, d_w, out.B2))) return rc;
+  if ((rc = run_one_msm<FqOps>(P, 3, d_w, out.C))) return rc;
+  if ((rc = run_one_msm<FqOps>(P, 4, P->d_p, out.H))) return rc;
+  G16_HIP(hipEventRecord(P->ev[5], P->st));
+  G16_HIP(hipEventSynchronize(P->ev[5]));
+  (void)hipEventElapsedTime(&P->tm.qap_ms, P->ev[2], P->ev[3]);
+  (void)hipEventElapsedTime(&P->tm.ntt_ms, P->ev[3], P->ev[4]);
+  (void)hipEventElapsedTime(&P->tm.total_ms, P->ev[2], P->ev[5]);
+  return G16_OK;
+}
+
+// Proof assembly on the host: O(1) work, ~1.5k field products.
+static int finish_impl(g16_prover* P, uint32_t slot, const Partial* parts, uint32_t count, const uint8_t* r_in,
+                       const uint8_t* s_in, g16_proof* out, uint8_t* pub) {
+  uint32_t r[8], s[8];
+  int rc;
+  if (r_in) memcpy(r, r_in, 32); else if ((rc = random_scalar(r))) return rc;
+  if (s_in) memcpy(s, s_in, 32); else if ((rc = random_scalar(s))) return rc;
+  if (!scalar_lt_r(r) || !scalar_lt_r(s)) { set_error("blinding scalar not reduced mod r"); return G16_E_ARG; }
+  Partial t = parts[0];
+  for (uint32_t k = 1; k < count; k++) {
+    xyzz_add(t.A, parts[k].A);
+    xyzz_add(t.B1, parts[k].B1);
+    xyzz_add(t.C, parts[k].C);
+    xyzz_add(t.H, parts[k].H);
+    xyzz_add(t.B2, parts[k].B2);
+  }
+  G1XYZZ tmp;
+  // pi_a = alpha1 + sum w_i A_i + r delta1
+  G1XYZZ pa = t.A;
+  xyzz_madd(pa, P->alpha1);
+  xyzz_mul_scalar(tmp, P->delta1, r);
+  xyzz_add(pa, tmp);
+  // pi_b = beta2 + sum w_i B2_i + s delta2
+  G2XYZZ pb = t.B2, tmp2;
+  xyzz_madd(pb, P->beta2);
+  xyzz_mul_scalar(tmp2, P->delta2, s);
+  xyzz_add(pb, tmp2);
+  // pib1 = beta1 + sum w_i B1_i + s delta1
+  G1XYZZ pb1 = t.B1;
+  xyzz_madd(pb1, P->beta1);
+  xyzz_mul_scalar(tmp, P->delta1, s);
+  xyzz_add(pb1, tmp);
+  G1Affine a_aff, b1_aff, c_aff;
+  G2Affine b_aff;
+  xyzz_to_affine(a_aff, pa);
+  xyzz_to_affine(b1_aff, pb1);
+  xyzz_to_affine(b_aff, pb);
+  // pi_c = sum_{i>p} w_i C_i + sum P_i H_i + s pi_a + r pib1 - (r s) delta1
+  G1XYZZ pc = t.C;
+  xyzz_add(pc, t.H);
+  xyzz_mul_scalar(tmp, a_aff, s);
+  xyzz_add(pc, tmp);
+  xyzz_mul_scalar(tmp, b1_aff, r);
+  xyzz_add(pc, tmp);
+  Fr rm, sm;
+  memcpy(rm.v, r, 32);
+  memcpy(sm.v, s, 32);
+  const Fr rs = fp_from_mont(fp_neg(fp_mul(fp_to_mont(rm), fp_to_mont(sm))));
+  xyzz_mul_scalar(tmp, P->delta1, rs.v);
+  xyzz_add(pc, tmp);
+  xyzz_to_affine(c_aff, pc);
+  g1_out(out->a, a_aff);
+  g2_out(out->b, b_aff);
+  g1_out(out->c, c_aff);
+  if (pub && P->nPublic) memcpy(pub, P->slot_pub[slot].data(), (size_t)P->nPublic * 32);
+  return G16_OK;
+}
+
+// ====================================================================== C ABI
+extern "C" {
+
+const char* g16_last_error(void) { return get_error(); }
+
+int g16_create(const uint8_t* zkey, size_t zkey_len, const g16_opts* opts, g16_prover** out) {
+  if (!out) { set_error("out is NULL"); return G16_E_ARG; }
+  *out = nullptr;
+  std::unique_ptr<g16_prover> P(new g16_prover());
+  int rc = create_impl(zkey, zkey_len, opts, P.get());
+  if (rc) return rc;
+  *out = P.release();
+  return G16_OK;
+}
+
+void g16_destroy(g16_prover* p) { delete p; }
+
+int g16_stage_witness(g16_prover* p, uint32_t slot, const uint8_t* wtns, size_t wtns_len) {
+  if (!p) { set_error("prover is NULL"); return G16_E_ARG; }
+  std::lock_guard<std::mutex> lk(p->mu);
+  return stage_impl(p, slot, wtns, wtns_len);
+}
+
+int g16_prove_partial(g16_prover* p, uint32_t slot, uint8_t partial[G16_PARTIAL_BYTES]) {
+  if (!p || !partial) { set_error("NULL argument"); return G16_E_ARG; }
+  std::lock_guard<std::mutex> lk(p->mu);
+  Partial part;
+  int rc = device_impl(p, slot, part);
+  if (rc) return rc;
+  memcpy(partial, &part, sizeof(part));
+  return G16_OK;
+}
+
+int g16_prove_finish(g16_prover* p, uint32_t slot, const uint8_t* partials, uint32_t count, const uint8_t r[32],
+                     const uint8_t s[32], g16_proof* out, uint8_t* pub) {
+  if (!p || !partials || !count || !out) { set_error("NULL argument"); return G16_E_ARG; }
+  std::lock_guard<std::mutex> lk(p->mu);
+  if (slot >= p->slot_pub.size()) { set_error("witness slot not staged"); return G16_E_STATE; }
+  std::vector<Partial> parts(count);
+  memcpy(parts.data(), partials, (size_t)count * sizeof(Partial));
+  return finish_impl(p, slot, parts.data(), count, r, s, out, pub);
+}
+
+int g16_prove_staged(g16_prover* p, uint32_t slot, const uint8_t r[32], const uint8_t s[32], g16_proof* out,
+                     uint8_t* pub) {
+  if (!p || !out) { set_error("NULL argument"); return G16_E_ARG; }
+  std::lock_guard<std::mutex> lk(p->mu);
+  if (p->shard_count != 1) { set_error("sharded handle: use g16_prove_partial/g16_prove_finish"); return G16_E_STATE; }
+  Partial part;
+  int rc = device_impl(p, slot, part);
+  if (rc) return rc;
+  return finish_impl(p, slot, &part, 1, r, s, out, pub);
+}
+
+int g16_prove(g16_prover* p, const uint8_t* wtns, size_t wtns_len, const uint8_t r[32], const uint8_t s[32],
+              g16_proof* out, uint8_t* pub) {
+  int rc = g16_stage_witness(p, 0, wtns, wtns_len);
+  if (rc) return rc;
+  return g16_prove_staged(p, 0, r, s, out, pub);
+}
+
+int g16_prove_batch(g16_prover* p, const uint8_t* const* wtns, const size_t* wtns_lens, size_t count,
+                    const uint8_t* rs, g16_proof* out, uint8_t* pub) {
+  if (!p || !wtns || !wtns_lens || !out) { set_error("NULL argument"); return G16_E_ARG; }
+  for (size_t i = 0; i < count; i++) {
+    int rc = g16_prove(p, wtns[i], wtns_lens[i], rs ? rs + i * 64 : nullptr, rs ? rs + i * 64 + 32 : nullptr,
+                       &out[i], pub ? pub + i * (size_t)p->nPublic * 32 : nullptr);
+    if (rc) return rc;
+  }
+  return G16_OK;
+}
+
+int g16_get_info(const g16_prover* p, g16_info* o) {
+  if (!p || !o) { set_error("NULL argument"); return G16_E_ARG; }
+  o->n_vars = p->nVars; o->n_public = p->nPublic; o->domain_size = p->N; o->n_coefs = p->nCoefs;
+  o->n_a = p->msm[0].n; o->n_b1 = p->msm[1].n; o->n_b2 = p->msm[2].n; o->n_c = p->msm[3].n; o->n_h = p->msm[4].n;
+  for (int i = 0; i < 5; i++) o->window_bits[i] = (uint32_t)p->msm[i].c;
+  return G16_OK;
+}
+
+int g16_get_timings(const g16_prover* p, g16_timings* o) {
+  if (!p || !o) { set_error("NULL argument"); return G16_E_ARG; }
+  *o = p->tm;
+  return G16_OK;
+}
+
+void g16_free(void* p) { free(p); }
+
+}  // extern "C"

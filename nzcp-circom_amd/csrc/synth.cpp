@@ -1,0 +1,518 @@
+// Test-only trapdoor Groth16 setup over a shape-matched synthetic R1CS (host code, threaded).
+//
+// Why it exists: the reference ships no .zkey/.wtns
+// (/root/reference/.gitignore:2-4,15-16) and its circuit cannot be compiled offline
+// (/root/reference/Makefile:14-19 fetches sha256-var-circom with curl), so benchmark- and
+// parity-sized proving keys are fabricated here with a known trapdoor, in snarkjs's zkey layout
+// (H basis App. C.3).  Plays the role of `snarkjs groth16 setup` [EXT] for tests.
+//
+// The generator follows, draw for draw, the spec in oracle/synth.py's docstring; tests check the
+// two produce byte-identical zkey/wtns for the same seed.  The arithmetic is the product's own
+// fp.cuh / ec.cuh compiled for the host.
+#include <stdlib.h>
+#include <string.h>
+
+#include <thread>
+
+#include "internal.h"
+
+namespace g16 {
+namespace {
+
+struct Xo {
+  uint64_t s[4];
+  explicit Xo(uint64_t seed) {
+    uint64_t z = seed;
+    for (int i = 0; i < 4; i++) {
+      z += 0x9E3779B97F4A7C15ull;
+      uint64_t x = z;
+      x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+      x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+      s[i] = x ^ (x >> 31);
+    }
+  }
+  static uint64_t rotl(uint64_t x, int k) { return (x << k) | (x >> (64 - k)); }
+  uint64_t next() {
+    const uint64_t res = rotl(s[1] * 5, 7) * 9;
+    const uint64_t t = s[1] << 17;
+    s[2] ^= s[0]; s[3] ^= s[1]; s[1] ^= s[2]; s[0] ^= s[3];
+    s[2] ^= t;
+    s[3] = rotl(s[3], 45);
+    return res;
+  }
+  uint64_t below(uint64_t k) { return next() % k; }
+  Fr rand_fr_std() {  // (u0 | u1<<64 | u2<<128 | u3<<192) mod r, standard form
+    Fr x;
+    for (int i = 0; i < 4; i++) {
+      const uint64_t u = next();
+      x.v[2 * i] = (uint32_t)u;
+      x.v[2 * i + 1] = (uint32_t)(u >> 32);
+    }
+    static const uint32_t R[8] = G16_FR_P;
+    for (;;) {  // 2^256 / r < 6
+      bool ge = true;
+      for (int i = 7; i >= 0; i--) {
+        if (x.v[i] > R[i]) break;
+        if (x.v[i] < R[i]) { ge = false; break; }
+      }
+      if (!ge) break;
+      int64_t br = 0;
+      for (int i = 0; i < 8; i++) {
+        br += (int64_t)x.v[i] - (int64_t)R[i];
+        x.v[i] = (uint32_t)br;
+        br >>= 32;
+      }
+    }
+    return x;
+  }
+  Fr rand_fr() { return fp_to_mont(rand_fr_std()); }  // Montgomery
+};
+
+using FrM = Fr;  // Montgomery-form Fr throughout this file
+
+FrM fr_u64(uint64_t v) {
+  Fr a = fp_zero<FrParams>();
+  a.v[0] = (uint32_t)v;
+  a.v[1] = (uint32_t)(v >> 32);
+  return fp_to_mont(a);
+}
+FrM fr_one() { return fp_one<FrParams>(); }
+FrM fr_neg_one() { return fp_neg(fp_one<FrParams>()); }
+
+FrM coef(Xo& rng) {
+  const uint64_t u = rng.below(100);
+  if (u < 40) return fr_one();
+  if (u < 80) return fr_neg_one();
+  if (u < 95) return fr_u64(1 + rng.below(65535));
+  return rng.rand_fr();
+}
+
+enum : uint8_t { CONST = 0, PUB, BIT, SMALL, SLACK };
+constexpr uint64_t EXP_EXAMPLE = 1951416330ull;
+
+struct Term { uint32_t s; FrM cf; };
+struct Circuit {
+  uint32_t n, p, m;
+  std::vector<uint8_t> cls;
+  std::vector<uint32_t> rowA, rowB, rowC;  // row offsets (m+1) into the term arrays
+  std::vector<Term> tA, tB, tC;
+  struct Slack { uint32_t row, sw, j1; FrM c1; };
+  std::vector<Slack> slacks;  // in constraint order
+};
+
+void gen_classes(Circuit& c, uint64_t seed) {
+  Xo rng(seed);
+  c.cls.assign(c.n, CONST);
+  for (uint32_t i = 1; i < c.n; i++) {
+    if (i <= c.p) c.cls[i] = PUB;
+    else {
+      const uint64_t u = rng.below(100);
+      c.cls[i] = u < 60 ? BIT : (u < 68 ? SMALL : SLACK);
+    }
+  }
+}
+
+void gen_circuit(Circuit& c, uint64_t seed) {
+  gen_classes(c, seed);
+  Xo rng(seed + 3);
+  const uint32_t n = c.n, p = c.p, m = c.m;
+  std::vector<uint32_t> slack, bits, rank(n, 0);
+  for (uint32_t i = 0; i < n; i++) {
+    if (c.cls[i] == SLACK) { rank[i] = (uint32_t)slack.size(); slack.push_back(i); }
+    if (((c.cls[i] == PUB && i < p) || c.cls[i] == BIT) && i % 20 < 7) bits.push_back(i);
+  }
+  if (bits.empty()) bits.push_back(0);
+  uint32_t nxt = 0;
+  auto fix = [&](uint32_t s) { return (c.cls[s] == SLACK && rank[s] >= nxt) ? 0u : s; };
+  auto pick = [&]() { return fix((uint32_t)rng.below(n)); };
+  auto pick_b = [&]() {
+    const uint32_t t = (uint32_t)rng.below(n);
+    uint32_t s = t - t % 20 + (uint32_t)rng.below(7);
+    if (s > n - 1) s = n - 1;
+    return fix(s);
+  };
+  c.rowA.assign(1, 0); c.rowB.assign(1, 0); c.rowC.assign(1, 0);
+  for (uint32_t r = 0; r < m; r++) {
+    const uint64_t u = rng.below(100);
+    const uint32_t rem = (uint32_t)slack.size() - nxt;
+    if (rem > 0 && (u < 32 || rem >= m - r)) {
+      const uint32_t sw = slack[nxt];
+      const uint32_t ta = 1 + (uint32_t)rng.below(4);
+      for (uint32_t k = 0; k < ta; k++) { const uint32_t s = pick(); c.tA.push_back({s, coef(rng)}); }
+      const uint32_t tb = 1 + (uint32_t)rng.below(2);
+      for (uint32_t k = 0; k < tb; k++) { const uint32_t s = pick_b(); c.tB.push_back({s, coef(rng)}); }
+      const uint32_t j1 = pick();
+      const FrM c1 = rng.rand_fr();
+      c.tC.push_back({sw, fr_one()});
+      c.tC.push_back({j1, c1});
+      c.slacks.push_back({r, sw, j1, c1});
+      nxt++;
+    } else {
+      const uint32_t x = bits[rng.below(bits.size())];
+      const uint32_t y = bits[rng.below(bits.size())];
+      const FrM ca = coef(rng), cb = coef(rng);
+      c.tA.push_back({x, ca});
+      c.tA.push_back({y, fp_neg(ca)});
+      c.tB.push_back({x, cb});
+      c.tB.push_back({y, cb});
+      c.tB.push_back({0, fp_neg(cb)});
+    }
+    c.rowA.push_back((uint32_t)c.tA.size());
+    c.rowB.push_back((uint32_t)c.tB.size());
+    c.rowC.push_back((uint32_t)c.tC.size());
+  }
+}
+
+// witness in Montgomery form
+void gen_witness(const Circuit& c, uint64_t wseed, std::vector<FrM>& w) {
+  Xo rng(wseed);
+  w.assign(c.n, fp_zero<FrParams>());
+  w[0] = fr_one();
+  for (uint32_t i = 1; i < c.n; i++) {
+    switch (c.cls[i]) {
+      case PUB: w[i] = fr_u64(i == c.p ? EXP_EXAMPLE : rng.below(2)); break;
+      case BIT: w[i] = fr_u64(rng.below(2)); break;
+      case SMALL: w[i] = fr_u64(rng.below(1024)); break;
+      default: w[i] = rng.rand_fr(); break;
+    }
+  }
+  for (const auto& sl : c.slacks) {
+    FrM a = fp_zero<FrParams>(), b = fp_zero<FrParams>();
+    for (uint32_t k = c.rowA[sl.row]; k < c.rowA[sl.row + 1]; k++) a = fp_add(a, fp_mul(c.tA[k].cf, w[c.tA[k].s]));
+    for (uint32_t k = c.rowB[sl.row]; k < c.rowB[sl.row + 1]; k++) b = fp_add(b, fp_mul(c.tB[k].cf, w[c.tB[k].s]));
+    w[sl.sw] = fp_sub(fp_mul(a, b), fp_mul(sl.c1, w[sl.j1]));
+  }
+}
+
+// ------------------------------------------------------------------ binfile writer
+struct Buf {
+  uint8_t* p = nullptr;
+  size_t len = 0, cap = 0;
+  bool reserve(size_t c) {
+    p = (uint8_t*)malloc(c ? c : 1);
+    cap = c;
+    return p != nullptr;
+  }
+  void put(const void* src, size_t n) { memcpy(p + len, src, n); len += n; }
+  void u32(uint32_t v) { put(&v, 4); }
+  void u64(uint64_t v) { put(&v, 8); }
+  uint8_t* skip(size_t n) { uint8_t* q = p + len; len += n; return q; }
+};
+
+void write_wtns(const std::vector<FrM>& w, Buf& b) {
+  const size_t n = w.size();
+  b.reserve(12 + 12 + 40 + 12 + n * 32);
+  b.put("wtns", 4); b.u32(2); b.u32(2);
+  b.u32(1); b.u64(40);
+  static const uint32_t R[8] = G16_FR_P;
+  b.u32(32); b.put(R, 32); b.u32((uint32_t)n);
+  b.u32(2); b.u64((uint64_t)n * 32);
+  for (size_t i = 0; i < n; i++) {
+    const Fr s = fp_from_mont(w[i]);
+    b.put(s.v, 32);
+  }
+}
+
+// ------------------------------------------------------------------ fixed-base multiplication
+template <class F> struct FixedBase {
+  int wb = 8, nwin = 32;
+  std::vector<Affine<F>> tbl;  // [nwin][2^wb - 1]
+  size_t row() const { return ((size_t)1 << wb) - 1; }
+};
+
+template <class F> void batch_to_affine(const XYZZ<F>* in, Affine<F>* out, size_t n) {
+  // one inversion per batch: x = X*(ZZ/ZZZ)^2, y = Y/ZZZ
+  std::vector<typename F::T> pref(n);
+  typename F::T acc = F::one();
+  for (size_t i = 0; i < n; i++) {
+    pref[i] = acc;
+    if (!xyzz_is_inf(in[i])) acc = F::mul(acc, in[i].zzz);
+  }
+  typename F::T inv = F::inv(acc);
+  for (size_t i = n; i-- > 0;) {
+    if (xyzz_is_inf(in[i])) { out[i].x = F::zero(); out[i].y = F::zero(); continue; }
+    const typename F::T zi = F::mul(inv, pref[i]);
+    inv = F::mul(inv, in[i].zzz);
+    const typename F::T zzi = F::sqr(F::mul(zi, in[i].zz));
+    out[i].x = F::mul(in[i].x, zzi);
+    out[i].y = F::mul(in[i].y, zi);
+  }
+}
+
+template <class Fn> void parallel_for(size_t n, int threads, Fn fn) {
+  if (threads < 1) threads = 1;
+  if ((size_t)threads > n) threads = n ? (int)n : 1;
+  std::vector<std::thread> th;
+  const size_t chunk = (n + threads - 1) / threads;
+  for (int t = 0; t < threads; t++) {
+    const size_t lo = (size_t)t * chunk, hi = lo + chunk < n ? lo + chunk : n;
+    if (lo >= hi) break;
+    th.emplace_back([=]() { fn(lo, hi); });
+  }
+  for (auto& x : th) x.join();
+}
+
+template <class F> void build_table(FixedBase<F>& fb, const Affine<F>& gen, int wb, int threads) {
+  fb.wb = wb;
+  fb.nwin = (254 + wb - 1) / wb;
+  const size_t row = fb.row();
+  fb.tbl.resize((size_t)fb.nwin * row);
+  std::vector<Affine<F>> bases(fb.nwin);
+  XYZZ<F> b;
+  xyzz_from_affine(b, gen);
+  for (int j = 0; j < fb.nwin; j++) {
+    xyzz_to_affine(bases[j], b);
+    for (int k = 0; k < wb; k++) xyzz_dbl(b);
+  }
+  parallel_for((size_t)fb.nwin, threads, [&](size_t lo, size_t hi) {
+    std::vector<XYZZ<F>> tmp(row);
+    for (size_t j = lo; j < hi; j++) {
+      XYZZ<F> acc;
+      xyzz_set_inf(acc);
+      for (size_t d = 0; d < row; d++) {
+        xyzz_madd(acc, bases[j]);
+        tmp[d] = acc;
+      }
+      batch_to_affine<F>(tmp.data(), &fb.tbl[j * row], row);
+    }
+  });
+}
+
+// out[i] = [k_i] G, k in Montgomery Fr; affine Montgomery bytes written at out + i*sizeof(Affine)
+template <class F>
+void fixed_mul_many(const FixedBase<F>& fb, const FrM* ks, size_t n, uint8_t* out, int threads) {
+  const size_t row = fb.row();
+  const uint32_t mask = (1u << fb.wb) - 1;
+  parallel_for(n, threads, [&](size_t lo, size_t hi) {
+    const size_t B = 512;
+    std::vector<XYZZ<F>> acc(B);
+    std::vector<Affine<F>> aff(B);
+    for (size_t base = lo; base < hi; base += B) {
+      const size_t cnt = base + B < hi ? B : hi - base;
+      for (size_t i = 0; i < cnt; i++) {
+        const Fr k = fp_from_mont(ks[base + i]);
+        XYZZ<F>& a = acc[i];
+        xyzz_set_inf(a);
+        for (int j = 0; j < fb.nwin; j++) {
+          const int pos = j * fb.wb;
+          uint64_t v = k.v[pos >> 5];
+          if ((pos >> 5) + 1 < 8) v |= (uint64_t)k.v[(pos >> 5) + 1] << 32;
+          const uint32_t d = (uint32_t)(v >> (pos & 31)) & mask;
+          if (d) xyzz_madd(a, fb.tbl[(size_t)j * row + d - 1]);
+        }
+      }
+      batch_to_affine<F>(acc.data(), aff.data(), cnt);
+      memcpy(out + base * sizeof(Affine<F>), aff.data(), cnt * sizeof(Affine<F>));
+    }
+  });
+}
+
+void batch_inverse(std::vector<FrM>& v) {
+  const size_t n = v.size();
+  std::vector<FrM> pref(n);
+  FrM acc = fr_one();
+  for (size_t i = 0; i < n; i++) { pref[i] = acc; acc = fp_mul(acc, v[i]); }
+  FrM inv = fp_inv(acc);
+  for (size_t i = n; i-- > 0;) {
+    const FrM t = fp_mul(inv, pref[i]);
+    inv = fp_mul(inv, v[i]);
+    v[i] = t;
+  }
+}
+
+FrM host_root(int L) {
+  Fr w = {G16_FR_W28};
+  for (int i = 28; i > L; i--) w = fp_sqr(w);
+  return w;
+}
+
+// L_c(tau) over the size-2^L domain, c = first, first+step, ... (count values)
+void lagrange_at(int L, const FrM& tau, size_t first, size_t step, size_t count, std::vector<FrM>& out) {
+  const size_t N = (size_t)1 << L;
+  const FrM w = host_root(L);
+  const FrM zt = fp_sub(fp_pow_u64(tau, N), fr_one());
+  const FrM scale = fp_mul(zt, fp_inv(fr_u64(N)));
+  const FrM wstep = fp_pow_u64(w, step);
+  std::vector<FrM> wc(count), den(count);
+  FrM cur = fp_pow_u64(w, first);
+  for (size_t i = 0; i < count; i++) {
+    wc[i] = cur;
+    den[i] = fp_sub(tau, cur);
+    cur = fp_mul(cur, wstep);
+  }
+  batch_inverse(den);
+  out.resize(count);
+  for (size_t i = 0; i < count; i++) out[i] = fp_mul(fp_mul(scale, wc[i]), den[i]);
+}
+
+}  // namespace
+}  // namespace g16
+
+using namespace g16;
+
+extern "C" int g16_synth_witness(uint32_t n, uint32_t p, uint32_t m, uint64_t seed, uint64_t wseed,
+                                 uint8_t** wtns, size_t* wtns_len) {
+  if (!wtns || !wtns_len || n < p + 1 || n < 2) { set_error("synth: bad arguments"); return G16_E_ARG; }
+  Circuit c;
+  c.n = n; c.p = p; c.m = m;
+  gen_circuit(c, seed);
+  std::vector<FrM> w;
+  gen_witness(c, wseed, w);
+  Buf b;
+  write_wtns(w, b);
+  *wtns = b.p;
+  *wtns_len = b.len;
+  return G16_OK;
+}
+
+extern "C" int g16_synth_setup(uint32_t n, uint32_t p, uint32_t m, uint64_t seed, int threads, uint8_t** zkey,
+                               size_t* zkey_len, uint8_t** wtns, size_t* wtns_len, uint8_t** vkey,
+                               size_t* vkey_len) {
+  if (!zkey || !zkey_len || n < p + 1 || n < 2 || m == 0) { set_error("synth: bad arguments"); return G16_E_ARG; }
+  if (threads <= 0) threads = (int)std::thread::hardware_concurrency();
+  if (threads <= 0) threads = 1;
+  Circuit c;
+  c.n = n; c.p = p; c.m = m;
+  gen_circuit(c, seed);
+  std::vector<FrM> w;
+  gen_witness(c, seed, w);
+  int L = 0;
+  while (((uint64_t)1 << L) < (uint64_t)m + p + 1) L++;
+  if (L > 27) { set_error("synth: circuit too large"); return G16_E_ARG; }
+  const size_t N = (size_t)1 << L;
+
+  // trapdoor (stream seed+1): tau, alpha, beta, gamma, delta, all non-zero
+  Xo trng(seed + 1);
+  FrM td[5];
+  for (int k = 0; k < 5;) {
+    const FrM v = trng.rand_fr();
+    if (!fp_is_zero(v)) td[k++] = v;
+  }
+  const FrM tau = td[0], alpha = td[1], beta = td[2], gamma = td[3], delta = td[4];
+  std::vector<FrM> Lg;
+  lagrange_at(L, tau, 0, 1, N, Lg);
+  std::vector<FrM> u(n, fp_zero<FrParams>()), v(n, fp_zero<FrParams>()), t(n, fp_zero<FrParams>());
+  const size_t ncoef = c.tA.size() + c.tB.size() + (size_t)p + 1;
+  // section 4 image: records in constraint order, A terms then B terms, then the binding rows
+  std::vector<uint8_t> s4(4 + ncoef * 44);
+  {
+    uint32_t nc32 = (uint32_t)ncoef;
+    memcpy(s4.data(), &nc32, 4);
+    uint8_t* q = s4.data() + 4;
+    auto rec = [&](uint32_t mm, uint32_t cc, uint32_t ss, const FrM& cf) {
+      memcpy(q, &mm, 4); memcpy(q + 4, &cc, 4); memcpy(q + 8, &ss, 4);
+      const Fr raw = fp_to_mont(cf);  // Montgomery(coef) * R = coef * R^2, stored as a plain integer
+      memcpy(q + 12, raw.v, 32);
+      q += 44;
+    };
+    for (uint32_t r = 0; r < m; r++) {
+      for (uint32_t k = c.rowA[r]; k < c.rowA[r + 1]; k++) {
+        rec(0, r, c.tA[k].s, c.tA[k].cf);
+        u[c.tA[k].s] = fp_add(u[c.tA[k].s], fp_mul(c.tA[k].cf, Lg[r]));
+      }
+      for (uint32_t k = c.rowB[r]; k < c.rowB[r + 1]; k++) {
+        rec(1, r, c.tB[k].s, c.tB[k].cf);
+        v[c.tB[k].s] = fp_add(v[c.tB[k].s], fp_mul(c.tB[k].cf, Lg[r]));
+      }
+      for (uint32_t k = c.rowC[r]; k < c.rowC[r + 1]; k++)
+        t[c.tC[k].s] = fp_add(t[c.tC[k].s], fp_mul(c.tC[k].cf, Lg[r]));
+    }
+    for (uint32_t i = 0; i <= p; i++) {
+      rec(0, m + i, i, fr_one());
+      u[i] = fp_add(u[i], Lg[m + i]);
+    }
+  }
+  const FrM ginv = fp_inv(gamma), dinv = fp_inv(delta);
+  std::vector<FrM> kic(p + 1), kc(n - p - 1), hs;
+  for (uint32_t i = 0; i < n; i++) {
+    const FrM kk = fp_add(fp_add(fp_mul(beta, u[i]), fp_mul(alpha, v[i])), t[i]);
+    if (i <= p) kic[i] = fp_mul(kk, ginv);
+    else kc[i - p - 1] = fp_mul(kk, dinv);
+  }
+  lagrange_at(L + 1, tau, 1, 2, N, hs);  // L^(2N)_{2i+1}(tau)
+  for (auto& x : hs) x = fp_mul(x, dinv);
+
+  const int wb = n >= 20000 ? 16 : 8;
+  FixedBase<FqOps> fb1;
+  FixedBase<Fq2Ops> fb2;
+  G1Affine g1;
+  g1.x = fp_one<FqParams>();
+  g1.y = fp_add(g1.x, g1.x);
+  G2Affine g2;
+  g2.x.a = Fq{G16_G2X0}; g2.x.b = Fq{G16_G2X1}; g2.y.a = Fq{G16_G2Y0}; g2.y.b = Fq{G16_G2Y1};
+  build_table(fb1, g1, wb, threads);
+  build_table(fb2, g2, wb, threads);
+
+  const size_t nC = (size_t)n - p - 1;
+  const size_t hdr2 = 4 + 32 + 4 + 32 + 12 + 64 + 64 + 128 + 128 + 64 + 128;
+  const size_t sizes[11] = {0, 4, hdr2, (size_t)(p + 1) * 64, s4.size(), (size_t)n * 64, (size_t)n * 64,
+                            (size_t)n * 128, nC * 64, N * 64, 64 + 4};
+  size_t total = 12;
+  for (int i = 1; i <= 10; i++) total += 12 + sizes[i];
+  Buf z;
+  if (!z.reserve(total)) { set_error("synth: out of memory"); return G16_E_STATE; }
+  z.put("zkey", 4); z.u32(1); z.u32(10);
+  auto sec = [&](uint32_t id) { z.u32(id); z.u64(sizes[id]); return z.skip(sizes[id]); };
+  uint8_t* p1 = sec(1);
+  { uint32_t one = 1; memcpy(p1, &one, 4); }
+  uint8_t* p2 = sec(2);
+  {
+    static const uint32_t Qp[8] = G16_FQ_P, Rp[8] = G16_FR_P;
+    uint32_t v32 = 32;
+    uint8_t* q = p2;
+    memcpy(q, &v32, 4); q += 4; memcpy(q, Qp, 32); q += 32;
+    memcpy(q, &v32, 4); q += 4; memcpy(q, Rp, 32); q += 32;
+    uint32_t dom = (uint32_t)N;
+    memcpy(q, &n, 4); memcpy(q + 4, &p, 4); memcpy(q + 8, &dom, 4); q += 12;
+    const FrM hk[3] = {alpha, beta, delta};
+    uint8_t g1pts[3 * 64], g2pts[3 * 128];
+    fixed_mul_many(fb1, hk, 3, g1pts, 1);
+    const FrM hk2[3] = {beta, gamma, delta};
+    fixed_mul_many(fb2, hk2, 3, g2pts, 1);
+    memcpy(q, g1pts, 64); q += 64;            // alpha1
+    memcpy(q, g1pts + 64, 64); q += 64;       // beta1
+    memcpy(q, g2pts, 128); q += 128;          // beta2
+    memcpy(q, g2pts + 128, 128); q += 128;    // gamma2
+    memcpy(q, g1pts + 128, 64); q += 64;      // delta1
+    memcpy(q, g2pts + 256, 128);              // delta2
+  }
+  uint8_t* p3 = sec(3);
+  fixed_mul_many(fb1, kic.data(), kic.size(), p3, threads);
+  uint8_t* p4 = sec(4);
+  memcpy(p4, s4.data(), s4.size());
+  uint8_t* p5 = sec(5);
+  fixed_mul_many(fb1, u.data(), n, p5, threads);
+  uint8_t* p6 = sec(6);
+  fixed_mul_many(fb1, v.data(), n, p6, threads);
+  uint8_t* p7 = sec(7);
+  fixed_mul_many(fb2, v.data(), n, p7, threads);
+  uint8_t* p8 = sec(8);
+  fixed_mul_many(fb1, kc.data(), kc.size(), p8, threads);
+  uint8_t* p9 = sec(9);
+  fixed_mul_many(fb1, hs.data(), hs.size(), p9, threads);
+  uint8_t* p10 = sec(10);
+  memset(p10, 0, sizes[10]);
+  *zkey = z.p;
+  *zkey_len = z.len;
+
+  if (wtns && wtns_len) {
+    Buf b;
+    write_wtns(w, b);
+    *wtns = b.p;
+    *wtns_len = b.len;
+  }
+  if (vkey && vkey_len) {
+    // alpha1 | beta2 | gamma2 | delta2 | IC[0..p]   (affine Montgomery LE)
+    Buf b;
+    b.reserve(64 + 3 * 128 + (size_t)(p + 1) * 64);
+    const uint8_t* h = p2 + 84;
+    b.put(h, 64);              // alpha1
+    b.put(h + 128, 128);       // beta2
+    b.put(h + 256, 128);       // gamma2
+    b.put(h + 448, 128);       // delta2
+    b.put(p3, (size_t)(p + 1) * 64);
+    *vkey = b.p;
+    *vkey_len = b.len;
+  }
+  return G16_OK;
+}
