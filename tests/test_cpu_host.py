@@ -1,0 +1,103 @@
+"""CPU suite for the product's host side: library loads and exports every declared symbol, the
+host-compiled product arithmetic (fp.cuh/ec.cuh) reproduces the oracle via the setup tool, the
+snarkjs error texts come out before any GPU is touched, and compute entry points refuse to run
+without a HIP device (no CPU fallback)."""
+import json
+import os
+import re
+
+import pytest
+
+import formats as f
+import groth16 as g
+import synth
+from conftest import ROOT, golden_path
+
+
+def test_library_exports_every_declared_symbol(amd):
+    hdr = open(os.path.join(ROOT, "include", "g16_prover.h")).read()
+    declared = set(re.findall(r"\b(g16_[a-z0-9_]+)\s*\(", hdr))
+    declared -= {"g16_opts", "g16_proof", "g16_info", "g16_timings"}
+    assert declared == set(amd.EXPORTS), declared ^ set(amd.EXPORTS)
+    lib = amd.load()
+    for name in declared:
+        assert getattr(lib, name) is not None
+
+
+@pytest.mark.parametrize("n,p,m,seed", [(24, 2, 12, 1), (150, 6, 120, 2), (333, 20, 300, 9)])
+def test_setup_tool_equals_python_oracle(amd, n, p, m, seed):
+    """Same seed => byte-identical zkey/wtns from the C++ tool (product fp/ec arithmetic on the
+    host, fixed-base tables, batch inversion) and from oracle/groth16.py + oracle/formats.py."""
+    zkey, wtns, vkey = amd.synth_setup(n, p, m, seed, 4)
+    rows, w = synth.make(n, p, m, seed)
+    zk, _ = g.setup(n, p, rows, g.trapdoor(seed + 1))
+    assert wtns == f.write_wtns(w)
+    assert zkey == f.write_zkey(zk)
+    exp_vk = f.g1_to_lem(zk["alpha1"]) + f.g2_to_lem(zk["beta2"]) + f.g2_to_lem(zk["gamma2"]) + \
+        f.g2_to_lem(zk["delta2"]) + b"".join(f.g1_to_lem(P) for P in zk["IC"])
+    assert vkey == exp_vk
+    w2 = amd.synth_witness(n, p, m, seed, 4242)
+    assert w2 == f.write_wtns(synth.make(n, p, m, seed, 4242)[1])
+
+
+def test_setup_tool_reproduces_golden(amd):
+    meta = json.load(open(golden_path("small.json")))
+    zkey, wtns, _ = amd.synth_setup(meta["n"], meta["p"], meta["m"], meta["seed"], 2)
+    assert zkey == open(golden_path("small.zkey"), "rb").read()
+    assert wtns == open(golden_path("small.wtns"), "rb").read()
+
+
+def test_setup_tool_wide_table_path(amd):
+    """n >= 20000 switches the fixed-base tables to 16-bit windows; spot-check points vs the oracle."""
+    import bn254 as b
+    n, p, m, seed = 20000, 3, 20, 31
+    zkey, _, _ = amd.synth_setup(n, p, m, seed, 8)
+    rows, _ = synth.make(n, p, m, seed)
+    td = g.trapdoor(seed + 1)
+    L = g.lagrange_at(32, td["tau"])
+    secs = f.read_binfile(zkey, "zkey", 2)
+    A = f.section(zkey, secs, 5)
+    u = {}
+    for c, (Ar, _, _) in enumerate(rows):
+        for s, cf in Ar:
+            u[s] = (u.get(s, 0) + cf * L[c]) % b.R
+    for i in range(p + 1):
+        u[i] = (u.get(i, 0) + L[m + i]) % b.R
+    for s in list(u)[:12]:
+        assert f.g1_from_lem(A[s * 64:(s + 1) * 64]) == b.G1.mul(b.G1_GEN, u[s])
+    assert A[64 * 19999:] == bytes(64) or 19999 in u
+
+
+def test_create_errors_match_snarkjs_without_gpu(amd):
+    zk = open(golden_path("tiny.zkey"), "rb").read()
+    with pytest.raises(amd.G16Error, match="zkey: Invalid File format"):
+        amd.Prover(b"wtns" + zk[4:])
+    bad = bytearray(zk); bad[4] = 9
+    with pytest.raises(amd.G16Error, match="Version not supported"):
+        amd.Prover(bytes(bad))
+    secs = f.read_binfile(zk, "zkey", 2)
+    bad = bytearray(zk); bad[secs[1][0][0]] = 2
+    with pytest.raises(amd.G16Error, match="zkey file is not groth16"):
+        amd.Prover(bytes(bad))
+    bad = bytearray(zk); bad[secs[2][0][0] + 4] ^= 1          # q of another curve
+    with pytest.raises(amd.G16Error, match="Curve not supported"):
+        amd.Prover(bytes(bad))
+    with pytest.raises(amd.G16Error, match="zkey: Invalid File format"):
+        amd.Prover(zk[:200])
+
+
+def test_no_cpu_fallback(amd):
+    """On a box without a HIP device every compute entry point must fail loudly."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present: covered by the -m gpu tests")
+    zk = open(golden_path("tiny.zkey"), "rb").read()
+    with pytest.raises(amd.G16Error) as e:
+        amd.Prover(zk)
+    assert e.value.code == -4
+    with pytest.raises(amd.G16Error) as e:
+        amd.fr_fft(bytes(64))
+    assert e.value.code == -4
+    with pytest.raises(amd.G16Error) as e:
+        amd.multiexp(1, bytes(64), bytes(32))
+    assert e.value.code == -4
