@@ -39,6 +39,8 @@ struct MsmWorkspace {
   void* d_seg = nullptr;
   void* d_red = nullptr;
   uint8_t* h_pinned = nullptr;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;  // around the bucket-accumulate kernel
+  float last_accum_ms = 0.f;
 };
 
 struct U256 { uint32_t v[8]; };
@@ -284,6 +286,7 @@ int msm_run_t(const MsmInstance& m, MsmWorkspace* ws, const Fr* d_scalars, uint8
               hipStream_t st) {
   using PT = XYZZ<F>;
   const uint32_t W = (uint32_t)m.W, B = m.nbuckets, nb = W * B;
+  ws->last_accum_ms = 0.f;
   if (m.n == 0) {
     memset(out_windows, 0, (size_t)W * sizeof(PT));
     return G16_OK;
@@ -299,9 +302,11 @@ int msm_run_t(const MsmInstance& m, MsmWorkspace* ws, const Fr* d_scalars, uint8
   msm_task_fill_kernel<<<(nb + 255) / 256, 256, 0, st>>>(ws->d_toff, nb, ws->d_task_bucket);
   // upper bound on tasks: every non-empty bucket has <= 1 short task + entries/task_len full ones
   const uint64_t max_tasks = (uint64_t)nb + ((uint64_t)m.n * W) / m.task_len;
+  G16_HIP(hipEventRecord(ws->ev0, st));
   msm_accumulate_kernel<F><<<(unsigned)((max_tasks + 63) / 64), 64, 0, st>>>(
       (const Affine<F>*)m.d_bases, ws->d_sorted, ws->d_off, ws->d_toff, nb, ws->d_task_bucket, m.task_len,
       (PT*)ws->d_partial);
+  G16_HIP(hipEventRecord(ws->ev1, st));
   msm_bucket_reduce_kernel<F><<<(W * nseg + 63) / 64, 64, 0, st>>>((const PT*)ws->d_partial, ws->d_toff, B,
                                                                    nseg, W, (PT*)ws->d_seg);
   // tree: d_seg (nseg per window) -> ... -> 1 per window, ping-pong between d_red halves
@@ -319,6 +324,7 @@ int msm_run_t(const MsmInstance& m, MsmWorkspace* ws, const Fr* d_scalars, uint8
   G16_HIP(hipGetLastError());
   G16_HIP(hipMemcpyAsync(ws->h_pinned, cur, (size_t)W * sizeof(PT), hipMemcpyDeviceToHost, st));
   G16_HIP(hipStreamSynchronize(st));
+  (void)hipEventElapsedTime(&ws->last_accum_ms, ws->ev0, ws->ev1);
   memcpy(out_windows, ws->h_pinned, (size_t)W * sizeof(PT));
   return G16_OK;
 }

@@ -93,6 +93,8 @@ int msm_workspace_create(MsmWorkspace** out, const MsmInstance* insts, int ninst
   G16_HIP(hipMalloc(&ws->d_seg, seg_bytes + 256));
   G16_HIP(hipMalloc(&ws->d_red, red_bytes + 256));
   G16_HIP(hipHostMalloc((void**)&ws->h_pinned, pin_bytes + 256));
+  G16_HIP(hipEventCreate(&ws->ev0));
+  G16_HIP(hipEventCreate(&ws->ev1));
   return G16_OK;
 }
 
@@ -103,10 +105,14 @@ void msm_workspace_destroy(MsmWorkspace* ws) {
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   if (ws->h_pinned) (void)hipHostFree(ws->h_pinned);
+  if (ws->ev0) (void)hipEventDestroy(ws->ev0);
+  if (ws->ev1) (void)hipEventDestroy(ws->ev1);
   delete ws;
 }
 
 int msm_run_g2(const MsmInstance& m, MsmWorkspace* ws, const Fr* d_scalars, uint8_t* out, hipStream_t st);
+
+float msm_last_accum_ms(const MsmWorkspace* ws) { return ws->last_accum_ms; }
 
 int msm_run(const MsmInstance& m, MsmWorkspace* ws, const Fr* d_scalars, uint8_t* out_windows,
             hipStream_t st) {

@@ -146,9 +146,9 @@ int ntt_tables_create(NttTables& t, int L, hipStream_t st) {
 }
 
 void ntt_tables_destroy(NttTables& t) {
-  if (t.tw_fwd) hipFree(t.tw_fwd);
-  if (t.tw_inv) hipFree(t.tw_inv);
-  if (t.coset) hipFree(t.coset);
+  if (t.tw_fwd) (void)hipFree(t.tw_fwd);
+  if (t.tw_inv) (void)hipFree(t.tw_inv);
+  if (t.coset) (void)hipFree(t.coset);
   t.tw_fwd = t.tw_inv = t.coset = nullptr;
   t.L = -1;
 }

@@ -352,6 +352,7 @@ static int run_one_msm(g16_prover* P, int i, const Fr* scalars, XYZZ<F>& out) {
   G16_HIP(hipEventRecord(e1, P->st));
   G16_HIP(hipEventSynchronize(e1));
   (void)hipEventElapsedTime(&P->tm.msm_ms[i], e0, e1);
+  P->tm.msm_accum_kernel_ms[i] = msm_last_accum_ms(P->ws);
   horner_windows<F>(out, P->winbuf.data(), P->msm[i].W, P->msm[i].c);
   return G16_OK;
 }

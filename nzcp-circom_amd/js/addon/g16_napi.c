@@ -1,0 +1,245 @@
+/*
+ * Thin raw-C N-API binding over the C ABI of libg16hip.so (include/g16_prover.h).
+ * Host code stays Node.js (BASELINE.json north_star); this file only marshals Buffers.
+ *
+ * snarkjs never blocks the event loop (its work runs in web-workers: ffjavascript threadman.js,
+ * pin /root/reference/yarn.lock:408-416), so create/prove run in napi async work and return
+ * Promises; nothing keeps the loop alive after the Promise settles (Threading).
+ *
+ * Exports:  create(zkey: Buffer, opts: {device, shardRank, shardCount, windowBits, taskLen}) -> Promise<handle>
+ *           prove(handle, wtns: Buffer, r: Buffer|null, s: Buffer|null) -> Promise<{proof: Buffer(256), pub: Buffer}>
+ *           info(handle) -> {nVars, nPublic, domainSize, nCoefs}
+ *           timings(handle) -> {...ms}
+ *           destroy(handle)
+ */
+#include <node_api.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "../../../include/g16_prover.h"
+
+#define NAPI_OK(call)                                                         \
+  do {                                                                        \
+    if ((call) != napi_ok) {                                                  \
+      napi_throw_error(env, NULL, "g16 addon: N-API call failed: " #call);    \
+      return NULL;                                                            \
+    }                                                                         \
+  } while (0)
+
+typedef struct {
+  g16_prover* p;
+} handle_t;
+
+static void handle_finalize(napi_env env, void* data, void* hint) {
+  handle_t* h = (handle_t*)data;
+  if (h->p) g16_destroy(h->p);
+  free(h);
+}
+
+typedef struct {
+  napi_async_work work;
+  napi_deferred deferred;
+  napi_ref refs[4];      /* keep input Buffers alive while the worker runs */
+  int nrefs;
+  /* create */
+  const uint8_t* zkey; size_t zkey_len; g16_opts opts; g16_prover* created;
+  /* prove */
+  handle_t* h; const uint8_t* wtns; size_t wtns_len; int have_r, have_s; uint8_t r[32], s[32];
+  g16_proof proof; uint8_t* pub; size_t pub_len;
+  int rc; char err[512];
+  int is_create;
+} job_t;
+
+static void job_execute(napi_env env, void* data) {
+  job_t* j = (job_t*)data;
+  if (j->is_create) {
+    j->rc = g16_create(j->zkey, j->zkey_len, &j->opts, &j->created);
+  } else {
+    j->rc = g16_prove(j->h->p, j->wtns, j->wtns_len, j->have_r ? j->r : NULL, j->have_s ? j->s : NULL,
+                      &j->proof, j->pub);
+  }
+  if (j->rc) {
+    strncpy(j->err, g16_last_error(), sizeof(j->err) - 1);   /* thread-local: read on the worker */
+    j->err[sizeof(j->err) - 1] = 0;
+  }
+}
+
+static void job_complete(napi_env env, napi_status status, void* data) {
+  job_t* j = (job_t*)data;
+  napi_value result;
+  if (status != napi_ok || j->rc) {
+    napi_value msg, err;
+    napi_create_string_utf8(env, j->rc ? j->err : "g16 addon: async work cancelled", NAPI_AUTO_LENGTH, &msg);
+    napi_create_error(env, NULL, msg, &err);
+    napi_reject_deferred(env, j->deferred, err);
+  } else if (j->is_create) {
+    handle_t* h = (handle_t*)calloc(1, sizeof(handle_t));
+    h->p = j->created;
+    napi_create_external(env, h, handle_finalize, NULL, &result);
+    napi_resolve_deferred(env, j->deferred, result);
+  } else {
+    napi_value proof, pub;
+    void* dst;
+    napi_create_object(env, &result);
+    napi_create_buffer_copy(env, sizeof(g16_proof), &j->proof, &dst, &proof);
+    napi_create_buffer_copy(env, j->pub_len, j->pub, &dst, &pub);
+    napi_set_named_property(env, result, "proof", proof);
+    napi_set_named_property(env, result, "pub", pub);
+    napi_resolve_deferred(env, j->deferred, result);
+  }
+  for (int i = 0; i < j->nrefs; i++) napi_delete_reference(env, j->refs[i]);
+  napi_delete_async_work(env, j->work);
+  free(j->pub);
+  free(j);
+}
+
+static int32_t get_i32(napi_env env, napi_value obj, const char* key, int32_t dflt) {
+  napi_value v;
+  napi_valuetype t;
+  bool has = false;
+  if (napi_has_named_property(env, obj, key, &has) != napi_ok || !has) return dflt;
+  if (napi_get_named_property(env, obj, key, &v) != napi_ok) return dflt;
+  if (napi_typeof(env, v, &t) != napi_ok || t != napi_number) return dflt;
+  int32_t out = dflt;
+  napi_get_value_int32(env, v, &out);
+  return out;
+}
+
+static napi_value queue_job(napi_env env, job_t* j, const char* name) {
+  napi_value promise, resname;
+  NAPI_OK(napi_create_promise(env, &j->deferred, &promise));
+  NAPI_OK(napi_create_string_utf8(env, name, NAPI_AUTO_LENGTH, &resname));
+  NAPI_OK(napi_create_async_work(env, NULL, resname, job_execute, job_complete, j, &j->work));
+  NAPI_OK(napi_queue_async_work(env, j->work));
+  return promise;
+}
+
+static napi_value js_create(napi_env env, napi_callback_info info) {
+  size_t argc = 2;
+  napi_value argv[2];
+  NAPI_OK(napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
+  bool isbuf = false;
+  if (argc < 1 || napi_is_buffer(env, argv[0], &isbuf) != napi_ok || !isbuf) {
+    napi_throw_type_error(env, NULL, "create(zkey: Buffer, opts)");
+    return NULL;
+  }
+  job_t* j = (job_t*)calloc(1, sizeof(job_t));
+  j->is_create = 1;
+  void* data;
+  NAPI_OK(napi_get_buffer_info(env, argv[0], &data, &j->zkey_len));
+  j->zkey = (const uint8_t*)data;
+  NAPI_OK(napi_create_reference(env, argv[0], 1, &j->refs[j->nrefs++]));
+  if (argc > 1) {
+    napi_valuetype t;
+    if (napi_typeof(env, argv[1], &t) == napi_ok && t == napi_object) {
+      j->opts.device = get_i32(env, argv[1], "device", 0);
+      j->opts.shard_rank = get_i32(env, argv[1], "shardRank", 0);
+      j->opts.shard_count = get_i32(env, argv[1], "shardCount", 1);
+      j->opts.window_bits = get_i32(env, argv[1], "windowBits", 0);
+      j->opts.task_len = get_i32(env, argv[1], "taskLen", 0);
+    }
+  }
+  return queue_job(env, j, "g16_create");
+}
+
+static napi_value js_prove(napi_env env, napi_callback_info info) {
+  size_t argc = 4;
+  napi_value argv[4];
+  NAPI_OK(napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
+  handle_t* h = NULL;
+  bool isbuf = false;
+  if (argc < 2 || napi_get_value_external(env, argv[0], (void**)&h) != napi_ok || !h || !h->p ||
+      napi_is_buffer(env, argv[1], &isbuf) != napi_ok || !isbuf) {
+    napi_throw_type_error(env, NULL, "prove(handle, wtns: Buffer, r, s)");
+    return NULL;
+  }
+  job_t* j = (job_t*)calloc(1, sizeof(job_t));
+  j->h = h;
+  void* data;
+  NAPI_OK(napi_get_buffer_info(env, argv[1], &data, &j->wtns_len));
+  j->wtns = (const uint8_t*)data;
+  NAPI_OK(napi_create_reference(env, argv[1], 1, &j->refs[j->nrefs++]));
+  NAPI_OK(napi_create_reference(env, argv[0], 1, &j->refs[j->nrefs++]));
+  for (int k = 0; k < 2; k++) {
+    if (argc > (size_t)(2 + k) && napi_is_buffer(env, argv[2 + k], &isbuf) == napi_ok && isbuf) {
+      size_t len;
+      NAPI_OK(napi_get_buffer_info(env, argv[2 + k], &data, &len));
+      if (len != 32) { free(j); napi_throw_range_error(env, NULL, "r and s must be 32-byte Buffers"); return NULL; }
+      memcpy(k == 0 ? j->r : j->s, data, 32);
+      if (k == 0) j->have_r = 1; else j->have_s = 1;
+    }
+  }
+  g16_info inf;
+  g16_get_info(h->p, &inf);
+  j->pub_len = (size_t)inf.n_public * 32;
+  j->pub = (uint8_t*)malloc(j->pub_len ? j->pub_len : 1);
+  return queue_job(env, j, "g16_prove");
+}
+
+static napi_value js_info(napi_env env, napi_callback_info info) {
+  size_t argc = 1;
+  napi_value argv[1], out, v;
+  handle_t* h = NULL;
+  NAPI_OK(napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
+  if (argc < 1 || napi_get_value_external(env, argv[0], (void**)&h) != napi_ok || !h || !h->p) {
+    napi_throw_type_error(env, NULL, "info(handle)");
+    return NULL;
+  }
+  g16_info inf;
+  g16_get_info(h->p, &inf);
+  NAPI_OK(napi_create_object(env, &out));
+  const char* keys[4] = {"nVars", "nPublic", "domainSize", "nCoefs"};
+  uint32_t vals[4] = {inf.n_vars, inf.n_public, inf.domain_size, inf.n_coefs};
+  for (int i = 0; i < 4; i++) {
+    NAPI_OK(napi_create_uint32(env, vals[i], &v));
+    NAPI_OK(napi_set_named_property(env, out, keys[i], v));
+  }
+  return out;
+}
+
+static napi_value js_timings(napi_env env, napi_callback_info info) {
+  size_t argc = 1;
+  napi_value argv[1], out, v;
+  handle_t* h = NULL;
+  NAPI_OK(napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
+  if (argc < 1 || napi_get_value_external(env, argv[0], (void**)&h) != napi_ok || !h || !h->p) {
+    napi_throw_type_error(env, NULL, "timings(handle)");
+    return NULL;
+  }
+  g16_timings t;
+  g16_get_timings(h->p, &t);
+  NAPI_OK(napi_create_object(env, &out));
+  const char* keys[4] = {"uploadMs", "qapMs", "nttMs", "totalMs"};
+  double vals[4] = {t.upload_ms, t.qap_ms, t.ntt_ms, t.total_ms};
+  for (int i = 0; i < 4; i++) {
+    NAPI_OK(napi_create_double(env, vals[i], &v));
+    NAPI_OK(napi_set_named_property(env, out, keys[i], v));
+  }
+  return out;
+}
+
+static napi_value js_destroy(napi_env env, napi_callback_info info) {
+  size_t argc = 1;
+  napi_value argv[1];
+  handle_t* h = NULL;
+  NAPI_OK(napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
+  if (argc >= 1 && napi_get_value_external(env, argv[0], (void**)&h) == napi_ok && h && h->p) {
+    g16_destroy(h->p);
+    h->p = NULL;
+  }
+  return NULL;
+}
+
+static napi_value init(napi_env env, napi_value exports) {
+  napi_property_descriptor props[] = {
+      {"create", NULL, js_create, NULL, NULL, NULL, napi_default, NULL},
+      {"prove", NULL, js_prove, NULL, NULL, NULL, napi_default, NULL},
+      {"info", NULL, js_info, NULL, NULL, NULL, napi_default, NULL},
+      {"timings", NULL, js_timings, NULL, NULL, NULL, napi_default, NULL},
+      {"destroy", NULL, js_destroy, NULL, NULL, NULL, napi_default, NULL},
+  };
+  NAPI_OK(napi_define_properties(env, exports, sizeof(props) / sizeof(props[0]), props));
+  return exports;
+}
+
+NAPI_MODULE(NODE_GYP_MODULE_NAME, init)

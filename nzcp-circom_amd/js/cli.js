@@ -1,0 +1,31 @@
+#!/usr/bin/env node
+// CLI twin of `snarkjs groth16 prove <circuit.zkey> <witness.wtns> <proof.json> <public.json>`
+// (snarkjs cli.js groth16Prove [EXT]; the reference's Makefile scripts the sibling PLONK lines,
+// /root/reference/Makefile:30-33).  Writes JSON.stringify(x, null, 1) like snarkjs.
+"use strict";
+const fs = require("fs");
+const { groth16 } = require("./index.js");
+
+async function main(argv) {
+  let a = argv.slice(2);
+  if (a[0] === "groth16") a = a.slice(1);
+  if (a[0] === "prove") a = a.slice(1);
+  const opts = {};
+  const pos = [];
+  for (let i = 0; i < a.length; i++) {
+    if (a[i] === "--r") opts.r = a[++i];
+    else if (a[i] === "--s") opts.s = a[++i];
+    else if (a[i] === "--device") opts.device = parseInt(a[++i], 10);
+    else pos.push(a[i]);
+  }
+  if (pos.length < 2) {
+    console.error("usage: cli.js [groth16] prove <circuit.zkey> <witness.wtns> [proof.json] [public.json] [--r dec --s dec --device n]");
+    process.exit(2);
+  }
+  const [zkey, wtns, proofFile = "proof.json", publicFile = "public.json"] = pos;
+  const { proof, publicSignals } = await groth16.prove(zkey, wtns, opts);
+  fs.writeFileSync(proofFile, JSON.stringify(proof, null, 1), "utf-8");
+  fs.writeFileSync(publicFile, JSON.stringify(publicSignals, null, 1), "utf-8");
+}
+
+main(process.argv).then(() => process.exit(0), (e) => { console.error(`[ERROR] snarkJS: ${e.message}`); process.exit(1); });

@@ -1,0 +1,112 @@
+// snarkjs-shaped host API over the MI355X prover (Node.js >= 12, N-API addon, no npm deps).
+//
+// Drop-in for the prove path of snarkjs 0.4.12 (pin /root/reference/yarn.lock:987-1001;
+// /root/reference/package.json:12):
+//     const { groth16 } = require("nzcp-circom_amd/js");
+//     const { proof, publicSignals } = await groth16.prove(zkey, wtns);
+// zkey / wtns: a path, a Buffer/Uint8Array, or snarkjs's {type: "mem", data: Uint8Array}.
+// proof / publicSignals have exactly snarkjs's shape (decimal strings; key order pi_a, pi_b, pi_c,
+// protocol, curve), so JSON.stringify(x, null, 1) reproduces proof.json / public.json byte for byte
+// given the same blinding (r, s).  Errors are thrown Errors with snarkjs's messages.
+// Extensions (not in snarkjs): opts = {r, s, device, windowBits}; groth16.createProver() keeps the
+// proving key resident in HBM across proofs; prover.proveBatch(wtnsList).
+"use strict";
+const fs = require("fs");
+const path = require("path");
+
+let addon = null;
+function native() {
+  if (!addon) {
+    const p = path.join(__dirname, "addon", "g16_napi.node");
+    if (!fs.existsSync(p)) throw new Error(`${p} not built (run make -C ${path.dirname(p)}); there is no JS fallback`);
+    addon = require(p);
+  }
+  return addon;
+}
+
+function toBuffer(x, what) {
+  if (typeof x === "string") return fs.readFileSync(x);
+  if (Buffer.isBuffer(x)) return x;
+  if (x instanceof Uint8Array) return Buffer.from(x.buffer, x.byteOffset, x.byteLength);
+  if (x && x.type === "mem" && x.data) return toBuffer(x.data, what);
+  throw new Error(`${what}: expected a path, a Buffer/Uint8Array or {type:"mem", data}`);
+}
+
+function scalarToBuffer(v) {
+  if (v === undefined || v === null) return null;
+  if (Buffer.isBuffer(v)) return v;
+  let n = BigInt(v);
+  const out = Buffer.alloc(32);
+  for (let i = 0; i < 32; i++) { out[i] = Number(n & 0xffn); n >>= 8n; }
+  return out;
+}
+
+function dec(buf, off) {
+  let n = 0n;
+  for (let i = 31; i >= 0; i--) n = (n << 8n) | BigInt(buf[off + i]);
+  return n.toString();
+}
+function isZero(buf, off, len) {
+  for (let i = 0; i < len; i++) if (buf[off + i]) return false;
+  return true;
+}
+
+// g16_proof bytes -> what snarkjs's G1/G2.toObject + stringifyBigInts produce
+function proofObject(raw) {
+  const g1 = (o) => (isZero(raw, o, 64) ? ["0", "1", "0"] : [dec(raw, o), dec(raw, o + 32), "1"]);
+  const pi_b = isZero(raw, 64, 128)
+    ? [["0", "0"], ["1", "0"], ["0", "0"]]
+    : [[dec(raw, 64), dec(raw, 96)], [dec(raw, 128), dec(raw, 160)], ["1", "0"]];
+  return { pi_a: g1(0), pi_b, pi_c: g1(192), protocol: "groth16", curve: "bn128" };
+}
+function publicSignals(pub) {
+  const out = [];
+  for (let o = 0; o < pub.length; o += 32) out.push(dec(pub, o));
+  return out;
+}
+
+class Prover {
+  constructor(handle) { this._h = handle; this._busy = Promise.resolve(); }
+  get info() { return native().info(this._h); }
+  get timings() { return native().timings(this._h); }
+  // one in-flight prove per handle: serialise callers
+  prove(wtns, opts = {}) {
+    const w = toBuffer(wtns, "wtns");
+    const run = () => native().prove(this._h, w, scalarToBuffer(opts.r), scalarToBuffer(opts.s))
+      .then(({ proof, pub }) => ({ proof: proofObject(proof), publicSignals: publicSignals(pub) }));
+    const p = this._busy.then(run, run);
+    this._busy = p.catch(() => {});
+    return p;
+  }
+  async proveBatch(wtnsList, opts = {}) {
+    const out = [];
+    for (const w of wtnsList) out.push(await this.prove(w, opts));
+    return out;
+  }
+  close() { if (this._h) { native().destroy(this._h); this._h = null; } }
+}
+
+async function createProver(zkey, opts = {}) {
+  const z = toBuffer(zkey, "zkey");
+  const h = await native().create(z, {
+    device: opts.device | 0, shardRank: opts.shardRank | 0, shardCount: opts.shardCount || 1,
+    windowBits: opts.windowBits | 0, taskLen: opts.taskLen | 0,
+  });
+  return new Prover(h);
+}
+
+const groth16 = {
+  // snarkjs: groth16.prove(zkeyFileName, witnessFileName[, logger]) -> {proof, publicSignals}
+  async prove(zkey, wtns, opts = {}) {
+    if (opts && typeof opts.debug === "function") opts = { logger: opts };   // snarkjs passes a logger third
+    const prover = await createProver(zkey, opts);
+    try {
+      return await prover.prove(wtns, opts);
+    } finally {
+      prover.close();
+    }
+  },
+  createProver,
+};
+
+module.exports = { groth16, createProver, Prover, proofObject, publicSignals };
