@@ -77,7 +77,7 @@ def fixed_rs(seed):
     return r.to_bytes(32, "little"), s_.to_bytes(32, "little")
 
 
-def cpu_leg(amd, args, full_proof, full_pub, full_vkey, log):
+def cpu_leg(amd, args, full_proof, full_pub, full_vkey, full_zkey, full_wtns, full_gpu_bytes, log):
     """cpu_baseline (rank 0, N = 1): time the oracle's C prover on a bounded sample, check the GPU
     against it bit-for-bit on that sample, pairing-verify the full-size GPU proof."""
     entry.oracle_path()
@@ -95,22 +95,32 @@ def cpu_leg(amd, args, full_proof, full_pub, full_vkey, log):
     except Exception:
         pass
     div = args.cpu_sample_div
-    n_s, m_s = max(args.n_vars // div, 600), max(args.n_constraints // div, 64)
-    zk, wt, _ = amd.synth_setup(n_s, args.n_public, m_s, SEED + 7, 0)
-    r, s = fixed_rs(SEED + 7)
     out = ctypes.create_string_buffer(256)
     pub = ctypes.create_string_buffer(max(1, args.n_public * 32))
-    t0 = time.time()
-    rc = olib.g16o_prove(zk, len(zk), wt, len(wt), r, s, out, pub, cores)
-    t_cpu = time.time() - t0
-    assert rc == 0, "oracle prover failed"
-    pv = amd.Prover(zk, device=0)
-    pr, gpub = amd.Proof(), ctypes.create_string_buffer(max(1, args.n_public * 32))
-    pv.stage(0, wt)
-    assert pv.prove_staged_raw(0, r, s, pr, gpub) == 0
-    gpu_bytes = bytes(pr.a) + bytes(pr.b) + bytes(pr.c)
-    sample_ok = (gpu_bytes == out.raw and gpub.raw == pub.raw)
-    pv.close()
+    if div <= 1:
+        # the sample IS the workload: same zkey, witness and blinding as the timed GPU steps
+        div, n_s = 1, args.n_vars
+        r, s = fixed_rs(SEED)
+        t0 = time.time()
+        rc = olib.g16o_prove(full_zkey, len(full_zkey), full_wtns, len(full_wtns), r, s, out, pub, cores)
+        t_cpu = time.time() - t0
+        assert rc == 0, "oracle prover failed"
+        sample_ok = (full_gpu_bytes == out.raw)
+    else:
+        n_s, m_s = max(args.n_vars // div, 600), max(args.n_constraints // div, 64)
+        zk, wt, _ = amd.synth_setup(n_s, args.n_public, m_s, SEED + 7, 0)
+        r, s = fixed_rs(SEED + 7)
+        t0 = time.time()
+        rc = olib.g16o_prove(zk, len(zk), wt, len(wt), r, s, out, pub, cores)
+        t_cpu = time.time() - t0
+        assert rc == 0, "oracle prover failed"
+        pv = amd.Prover(zk, device=0)
+        pr, gpub = amd.Proof(), ctypes.create_string_buffer(max(1, args.n_public * 32))
+        pv.stage(0, wt)
+        assert pv.prove_staged_raw(0, r, s, pr, gpub) == 0
+        gpu_bytes = bytes(pr.a) + bytes(pr.b) + bytes(pr.c)
+        sample_ok = (gpu_bytes == out.raw and gpub.raw == pub.raw)
+        pv.close()
     log(f"cpu sample n={n_s}: {t_cpu:.2f}s on {cores} threads; GPU==CPU proof bytes: {sample_ok}")
     assert sample_ok, "GPU proof differs from the CPU oracle on the sample circuit"
     # pairing check of the full-size GPU proof against the verification key of the setup
@@ -125,9 +135,10 @@ def cpu_leg(amd, args, full_proof, full_pub, full_vkey, log):
     log(f"full-size proof pairing check: {verified}")
     assert verified, "full-size GPU proof failed the pairing check"
     return {"value": round(1.0 / (t_cpu * div), 5), "unit": "proofs/s", "cores": cores, "kind": "port",
-            "sample": f"oracle/c OpenMP prover, one proof of the 1/{div}-size circuit (nVars={n_s}) in "
-                      f"{t_cpu:.2f}s, scaled x{div} linearly to the full workload; GPU proof of the sample "
-                      f"bit-identical; full-size proof pairing-verified",
+            "sample": (f"oracle/c OpenMP prover (in-repo CPU port, not snarkjs), one proof of "
+                       + ("the full workload" if div == 1 else f"the 1/{div}-size circuit, scaled x{div} linearly")
+                       + f" (nVars={n_s}) in {t_cpu:.2f}s on {cores} threads; GPU proof bit-identical to it; "
+                         f"full-size GPU proof pairing-verified"),
             "sample_seconds": round(t_cpu, 3)}
 
 
@@ -142,7 +153,7 @@ def main():
     ap.add_argument("--mode", choices=["shard", "replicas"], default="shard")
     ap.add_argument("--window-bits", type=int, default=0)
     ap.add_argument("--task-len", type=int, default=0)
-    ap.add_argument("--cpu-sample-div", type=int, default=8)
+    ap.add_argument("--cpu-sample-div", type=int, default=1)
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     args = ap.parse_args()
 
@@ -174,7 +185,8 @@ def main():
     prover = amd.Prover(zkey, device=local, shard_rank=rank if sharded else 0,
                         shard_count=world if sharded else 1, window_bits=args.window_bits,
                         task_len=args.task_len)
-    del zkey
+    if world > 1 or args.no_cpu:
+        zkey = None
     info = prover.info
     log(f"g16_create: {time.time() - t0:.1f}s; domain 2^{info.domain_size.bit_length() - 1}, nCoefs {info.n_coefs}, "
         f"resident bases A/B1/B2/C/H = {info.n_a}/{info.n_b1}/{info.n_b2}/{info.n_c}/{info.n_h}, "
@@ -267,7 +279,9 @@ def main():
                          "note": "integer-VALU bound (~1.4k v_mad_u64_u32 per 96-byte point), see DESIGN.md"},
         }
         if world == 1 and not args.no_cpu:
-            out["cpu_baseline"] = cpu_leg(amd, args, proof_obj, pub_list, vkey, log)
+            gpu_bytes = bytes(pr.a) + bytes(pr.b) + bytes(pr.c)
+            prover.close()
+            out["cpu_baseline"] = cpu_leg(amd, args, proof_obj, pub_list, vkey, zkey, wtns, gpu_bytes, log)
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out), flush=True)

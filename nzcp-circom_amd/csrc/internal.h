@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stddef.h>
 #include <stdint.h>
+#include <string.h>
 #include <string>
 #include <vector>
 
@@ -85,9 +86,26 @@ void msm_instance_destroy(MsmInstance& m);
 int msm_workspace_create(MsmWorkspace** ws, const MsmInstance* insts, int ninst);
 void msm_workspace_destroy(MsmWorkspace* ws);
 // Runs the MSM of `m` against scalars d_scalars (standard form, 32 B each) and writes the W
-// per-window sums (XYZZ, Montgomery) to host memory out_windows (W * msm_point_bytes).
+// per-window sums (XYZZ, Montgomery) to host memory out_windows: (W + 1) * msm_point_bytes, the
+// last entry being the unweighted sum of the scalar == 1 points (combine: msm.cuh msm_combine_windows).
 float msm_last_accum_ms(const MsmWorkspace* ws);
 int msm_run(const MsmInstance& m, MsmWorkspace* ws, const Fr* d_scalars, uint8_t* out_windows,
             hipStream_t st);
+
+// total = sum_j 2^(c j) * windows[j]  (Horner, c doublings per window) + windows[W] (ones window)
+template <class F> inline void msm_combine_windows(XYZZ<F>& total, const uint8_t* windows, int W, int c) {
+  xyzz_set_inf(total);
+  for (int j = W - 1; j >= 0; j--) {
+    if (!xyzz_is_inf(total))
+      for (int k = 0; k < c; k++) xyzz_dbl(total);
+    XYZZ<F> w;
+    memcpy(&w, windows + (size_t)j * sizeof(XYZZ<F>), sizeof(w));
+    xyzz_add(total, w);
+  }
+  XYZZ<F> ones;
+  memcpy(&ones, windows + (size_t)W * sizeof(XYZZ<F>), sizeof(ones));
+  xyzz_add(total, ones);
+}
+
 
 }  // namespace g16

@@ -35,6 +35,8 @@ struct MsmWorkspace {
   uint32_t* d_toff = nullptr;
   uint32_t* d_sorted = nullptr;
   uint32_t* d_task_bucket = nullptr;
+  uint32_t* d_tile_a = nullptr;
+  uint32_t* d_tile_b = nullptr;
   void* d_partial = nullptr;
   void* d_seg = nullptr;
   void* d_red = nullptr;
@@ -86,18 +88,14 @@ static __global__ __launch_bounds__(256) void msm_count_kernel(const Fr* __restr
                                                         const uint32_t* __restrict__ src, uint32_t n,
                                                         int c, int W, U256 K, uint32_t* __restrict__ cnt) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
   uint32_t s[8];
-  bool one = false;
-  const bool live = i < n;
-  if (live) one = msm_load_scalar(scalars, src, i, K, s);
+  const bool one = msm_load_scalar(scalars, src, i, K, s);
   const uint32_t B = 1u << (c - 1);
-  // value 1 -> key 0 (window 0, |digit| 1): aggregate across the wave
-  const unsigned long long m = __ballot(live && one);
-  if (m) {
-    const int lane = threadIdx.x & 63;
-    if (live && one && (m & ((1ull << lane) - 1)) == 0) atomicAdd(&cnt[0], (uint32_t)__popcll(m));
+  if (one) {  // the "ones" pseudo-window: unweighted buckets, spread by point index
+    atomicAdd(&cnt[(uint32_t)W * B + (i & (B - 1))], 1u);
+    return;
   }
-  if (!live || one) return;
   for (int j = 0; j < W; j++) {
     uint32_t neg;
     const uint32_t key = msm_key(s, j, c, W, B, neg);
@@ -110,21 +108,14 @@ static __global__ __launch_bounds__(256) void msm_scatter_kernel(const Fr* __res
                                                           int c, int W, U256 K, uint32_t* __restrict__ cursor,
                                                           uint32_t* __restrict__ sorted) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
   uint32_t s[8];
-  bool one = false;
-  const bool live = i < n;
-  if (live) one = msm_load_scalar(scalars, src, i, K, s);
+  const bool one = msm_load_scalar(scalars, src, i, K, s);
   const uint32_t B = 1u << (c - 1);
-  const unsigned long long m = __ballot(live && one);
-  if (m) {
-    const int lane = threadIdx.x & 63;
-    const int leader = __ffsll((long long)m) - 1;
-    uint32_t base = 0;
-    if (lane == leader) base = atomicAdd(&cursor[0], (uint32_t)__popcll(m));
-    base = __shfl(base, leader, 64);
-    if (live && one) sorted[base + (uint32_t)__popcll(m & ((1ull << lane) - 1))] = i;
+  if (one) {
+    sorted[atomicAdd(&cursor[(uint32_t)W * B + (i & (B - 1))], 1u)] = i;
+    return;
   }
-  if (!live || one) return;
   for (int j = 0; j < W; j++) {
     uint32_t neg;
     const uint32_t key = msm_key(s, j, c, W, B, neg);
@@ -135,42 +126,97 @@ static __global__ __launch_bounds__(256) void msm_scatter_kernel(const Fr* __res
   }
 }
 
-// Single-workgroup exclusive scans: off = scan(cnt), toff = scan(ceil(cnt/task_len)); cursor = off.
-static __global__ __launch_bounds__(1024) void msm_scan_kernel(const uint32_t* __restrict__ cnt, uint32_t nb,
-                                                        uint32_t task_len, uint32_t* __restrict__ off,
-                                                        uint32_t* __restrict__ cursor,
-                                                        uint32_t* __restrict__ toff) {
-  __shared__ uint32_t sh_a[1024], sh_b[1024];
-  const uint32_t tid = threadIdx.x;
-  const uint32_t chunk = (nb + 1023) / 1024;
-  const uint32_t lo = tid * chunk, hi = (lo + chunk < nb) ? lo + chunk : nb;
+// Exclusive scans off = scan(cnt), toff = scan(ceil(cnt/task_len)), cursor = off, in three launches:
+// per-tile sums (2048 counters per workgroup) -> one workgroup scans the tile sums -> per-tile
+// local scan + tile offset.
+static constexpr uint32_t kScanTile = 2048;   // 256 threads x 8 counters
+
+static __global__ __launch_bounds__(256) void msm_scan_tiles_kernel(const uint32_t* __restrict__ cnt, uint32_t nb,
+                                                             uint32_t task_len, uint32_t* __restrict__ tile_a,
+                                                             uint32_t* __restrict__ tile_b) {
+  __shared__ uint32_t sh_a[256], sh_b[256];
+  const uint32_t tid = threadIdx.x, base = blockIdx.x * kScanTile + tid * 8;
   uint32_t sa = 0, sb = 0;
-  for (uint32_t k = lo; k < hi; k++) {
-    const uint32_t v = cnt[k];
+#pragma unroll
+  for (int k = 0; k < 8; k++) {
+    const uint32_t v = (base + k < nb) ? cnt[base + k] : 0u;
     sa += v;
     sb += (v + task_len - 1) / task_len;
   }
-  sh_a[tid] = sa;
-  sh_b[tid] = sb;
+  sh_a[tid] = sa; sh_b[tid] = sb;
+  __syncthreads();
+  for (uint32_t d = 128; d > 0; d >>= 1) {
+    if (tid < d) { sh_a[tid] += sh_a[tid + d]; sh_b[tid] += sh_b[tid + d]; }
+    __syncthreads();
+  }
+  if (tid == 0) { tile_a[blockIdx.x] = sh_a[0]; tile_b[blockIdx.x] = sh_b[0]; }
+}
+
+// ntiles <= 1024 * chunk; one workgroup; writes exclusive tile offsets in place and the totals
+static __global__ __launch_bounds__(1024) void msm_scan_top_kernel(uint32_t* __restrict__ tile_a,
+                                                            uint32_t* __restrict__ tile_b, uint32_t ntiles,
+                                                            uint32_t* __restrict__ total_a,
+                                                            uint32_t* __restrict__ total_b) {
+  __shared__ uint32_t sh_a[1024], sh_b[1024];
+  const uint32_t tid = threadIdx.x;
+  const uint32_t chunk = (ntiles + 1023) / 1024;
+  const uint32_t lo = tid * chunk, hi = (lo + chunk < ntiles) ? lo + chunk : ntiles;
+  uint32_t sa = 0, sb = 0;
+  for (uint32_t k = lo; k < hi; k++) { sa += tile_a[k]; sb += tile_b[k]; }
+  sh_a[tid] = sa; sh_b[tid] = sb;
   __syncthreads();
   for (uint32_t d = 1; d < 1024; d <<= 1) {
     uint32_t va = 0, vb = 0;
     if (tid >= d) { va = sh_a[tid - d]; vb = sh_b[tid - d]; }
     __syncthreads();
-    sh_a[tid] += va;
-    sh_b[tid] += vb;
+    sh_a[tid] += va; sh_b[tid] += vb;
     __syncthreads();
   }
-  uint32_t pa = sh_a[tid] - sa, pb = sh_b[tid] - sb;  // exclusive prefix of this chunk
+  uint32_t pa = sh_a[tid] - sa, pb = sh_b[tid] - sb;
   for (uint32_t k = lo; k < hi; k++) {
-    const uint32_t v = cnt[k];
-    off[k] = pa;
-    cursor[k] = pa;
-    toff[k] = pb;
-    pa += v;
-    pb += (v + task_len - 1) / task_len;
+    const uint32_t va = tile_a[k], vb = tile_b[k];
+    tile_a[k] = pa; tile_b[k] = pb;
+    pa += va; pb += vb;
   }
-  if (tid == 1023) { off[nb] = sh_a[1023]; toff[nb] = sh_b[1023]; }
+  if (tid == 1023) { *total_a = sh_a[1023]; *total_b = sh_b[1023]; }
+}
+
+static __global__ __launch_bounds__(256) void msm_scan_apply_kernel(const uint32_t* __restrict__ cnt, uint32_t nb,
+                                                             uint32_t task_len,
+                                                             const uint32_t* __restrict__ tile_a,
+                                                             const uint32_t* __restrict__ tile_b,
+                                                             uint32_t* __restrict__ off,
+                                                             uint32_t* __restrict__ cursor,
+                                                             uint32_t* __restrict__ toff) {
+  __shared__ uint32_t sh_a[256], sh_b[256];
+  const uint32_t tid = threadIdx.x, base = blockIdx.x * kScanTile + tid * 8;
+  uint32_t v[8], sa = 0, sb = 0;
+#pragma unroll
+  for (int k = 0; k < 8; k++) {
+    v[k] = (base + k < nb) ? cnt[base + k] : 0u;
+    sa += v[k];
+    sb += (v[k] + task_len - 1) / task_len;
+  }
+  sh_a[tid] = sa; sh_b[tid] = sb;
+  __syncthreads();
+  for (uint32_t d = 1; d < 256; d <<= 1) {
+    uint32_t va = 0, vb = 0;
+    if (tid >= d) { va = sh_a[tid - d]; vb = sh_b[tid - d]; }
+    __syncthreads();
+    sh_a[tid] += va; sh_b[tid] += vb;
+    __syncthreads();
+  }
+  uint32_t pa = tile_a[blockIdx.x] + sh_a[tid] - sa, pb = tile_b[blockIdx.x] + sh_b[tid] - sb;
+#pragma unroll
+  for (int k = 0; k < 8; k++) {
+    if (base + k < nb) {
+      off[base + k] = pa;
+      cursor[base + k] = pa;
+      toff[base + k] = pb;
+    }
+    pa += v[k];
+    pb += (v[k] + task_len - 1) / task_len;
+  }
 }
 
 static __global__ __launch_bounds__(256) void msm_task_fill_kernel(const uint32_t* __restrict__ toff, uint32_t nb,
@@ -216,15 +262,16 @@ __device__ __forceinline__ void msm_mul_small(XYZZ<F>& r, const XYZZ<F>& p, uint
   }
 }
 
-// seg[j*nseg + g] = sum_{bi in segment g of window j} (bi+1) * S_bi
+// seg[j*nseg + g] = sum_{bi in segment g of window j} (bi+1) * S_bi   (j < W);  j == W: sum S_bi
 template <class F>
 __global__ __launch_bounds__(64) void msm_bucket_reduce_kernel(const XYZZ<F>* __restrict__ partial,
                                                                const uint32_t* __restrict__ toff, uint32_t B,
                                                                uint32_t nseg, uint32_t W,
                                                                XYZZ<F>* __restrict__ seg) {
   const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
-  if (tid >= W * nseg) return;
+  if (tid >= (W + 1) * nseg) return;
   const uint32_t j = tid / nseg, g = tid % nseg;
+  const bool plain = (j == W);   // the "ones" pseudo-window: plain sum of its buckets
   const uint32_t lo = g * kSegLen;
   const uint32_t hi = (lo + kSegLen < B) ? lo + kSegLen : B;
   XYZZ<F> run, acc;
@@ -236,9 +283,11 @@ __global__ __launch_bounds__(64) void msm_bucket_reduce_kernel(const XYZZ<F>* __
       const XYZZ<F> s = partial[t];
       xyzz_add(run, s);
     }
-    xyzz_add(acc, run);
+    if (!plain) xyzz_add(acc, run);
   }
-  if (lo != 0) {
+  if (plain) {
+    acc = run;
+  } else if (lo != 0) {
     XYZZ<F> m;
     msm_mul_small(m, run, lo);
     xyzz_add(acc, m);
@@ -285,10 +334,10 @@ template <class F>
 int msm_run_t(const MsmInstance& m, MsmWorkspace* ws, const Fr* d_scalars, uint8_t* out_windows,
               hipStream_t st) {
   using PT = XYZZ<F>;
-  const uint32_t W = (uint32_t)m.W, B = m.nbuckets, nb = W * B;
+  const uint32_t W = (uint32_t)m.W, B = m.nbuckets, WT = W + 1, nb = WT * B;  // + the ones window
   ws->last_accum_ms = 0.f;
   if (m.n == 0) {
-    memset(out_windows, 0, (size_t)W * sizeof(PT));
+    memset(out_windows, 0, (size_t)WT * sizeof(PT));
     return G16_OK;
   }
   const uint32_t nseg = (B + kSegLen - 1) / kSegLen;
@@ -297,35 +346,39 @@ int msm_run_t(const MsmInstance& m, MsmWorkspace* ws, const Fr* d_scalars, uint8
   G16_HIP(hipMemsetAsync(ws->d_cnt, 0, (size_t)(nb + 1) * 4, st));
   const uint32_t nblk = (m.n + 255) / 256;
   msm_count_kernel<<<nblk, 256, 0, st>>>(d_scalars, m.d_src, m.n, m.c, m.W, K, ws->d_cnt);
-  msm_scan_kernel<<<1, 1024, 0, st>>>(ws->d_cnt, nb, m.task_len, ws->d_off, ws->d_cursor, ws->d_toff);
+  const uint32_t ntiles = (nb + kScanTile - 1) / kScanTile;
+  msm_scan_tiles_kernel<<<ntiles, 256, 0, st>>>(ws->d_cnt, nb, m.task_len, ws->d_tile_a, ws->d_tile_b);
+  msm_scan_top_kernel<<<1, 1024, 0, st>>>(ws->d_tile_a, ws->d_tile_b, ntiles, ws->d_off + nb, ws->d_toff + nb);
+  msm_scan_apply_kernel<<<ntiles, 256, 0, st>>>(ws->d_cnt, nb, m.task_len, ws->d_tile_a, ws->d_tile_b, ws->d_off,
+                                                ws->d_cursor, ws->d_toff);
   msm_scatter_kernel<<<nblk, 256, 0, st>>>(d_scalars, m.d_src, m.n, m.c, m.W, K, ws->d_cursor, ws->d_sorted);
   msm_task_fill_kernel<<<(nb + 255) / 256, 256, 0, st>>>(ws->d_toff, nb, ws->d_task_bucket);
   // upper bound on tasks: every non-empty bucket has <= 1 short task + entries/task_len full ones
-  const uint64_t max_tasks = (uint64_t)nb + ((uint64_t)m.n * W) / m.task_len;
+  const uint64_t max_tasks = (uint64_t)nb + ((uint64_t)m.n * W) / m.task_len;  // ones: <= n entries, covered
   G16_HIP(hipEventRecord(ws->ev0, st));
   msm_accumulate_kernel<F><<<(unsigned)((max_tasks + 63) / 64), 64, 0, st>>>(
       (const Affine<F>*)m.d_bases, ws->d_sorted, ws->d_off, ws->d_toff, nb, ws->d_task_bucket, m.task_len,
       (PT*)ws->d_partial);
   G16_HIP(hipEventRecord(ws->ev1, st));
-  msm_bucket_reduce_kernel<F><<<(W * nseg + 63) / 64, 64, 0, st>>>((const PT*)ws->d_partial, ws->d_toff, B,
+  msm_bucket_reduce_kernel<F><<<(WT * nseg + 63) / 64, 64, 0, st>>>((const PT*)ws->d_partial, ws->d_toff, B,
                                                                    nseg, W, (PT*)ws->d_seg);
   // tree: d_seg (nseg per window) -> ... -> 1 per window, ping-pong between d_red halves
   PT* cur = (PT*)ws->d_seg;
   uint32_t cnt = nseg;
-  PT* bufs[2] = {(PT*)ws->d_red, (PT*)ws->d_red + (size_t)W * ((nseg + 63) / 64)};
+  PT* bufs[2] = {(PT*)ws->d_red, (PT*)ws->d_red + (size_t)WT * ((nseg + 63) / 64)};
   int flip = 0;
   while (cnt > 1) {
     const uint32_t nout = (cnt + 63) / 64;
-    msm_wave_reduce_kernel<F><<<dim3(nout, W), 64, 0, st>>>(cur, cnt, bufs[flip], nout);
+    msm_wave_reduce_kernel<F><<<dim3(nout, WT), 64, 0, st>>>(cur, cnt, bufs[flip], nout);
     cur = bufs[flip];
     flip ^= 1;
     cnt = nout;
   }
   G16_HIP(hipGetLastError());
-  G16_HIP(hipMemcpyAsync(ws->h_pinned, cur, (size_t)W * sizeof(PT), hipMemcpyDeviceToHost, st));
+  G16_HIP(hipMemcpyAsync(ws->h_pinned, cur, (size_t)WT * sizeof(PT), hipMemcpyDeviceToHost, st));
   G16_HIP(hipStreamSynchronize(st));
   (void)hipEventElapsedTime(&ws->last_accum_ms, ws->ev0, ws->ev1);
-  memcpy(out_windows, ws->h_pinned, (size_t)W * sizeof(PT));
+  memcpy(out_windows, ws->h_pinned, (size_t)WT * sizeof(PT));
   return G16_OK;
 }
 

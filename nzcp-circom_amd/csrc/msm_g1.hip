@@ -68,7 +68,7 @@ int msm_workspace_create(MsmWorkspace** out, const MsmInstance* insts, int ninst
   size_t part_bytes = 0, seg_bytes = 0, red_bytes = 0, pin_bytes = 0;
   for (int i = 0; i < ninst; i++) {
     const MsmInstance& m = insts[i];
-    const uint64_t nb = (uint64_t)m.W * m.nbuckets;
+    const uint64_t nb = (uint64_t)(m.W + 1) * m.nbuckets;   // + the ones window
     const uint64_t entries = (uint64_t)m.n * m.W;
     const uint64_t tasks = nb + entries / m.task_len + 64;
     const uint64_t nseg = (m.nbuckets + kSegLen - 1) / kSegLen;
@@ -77,10 +77,10 @@ int msm_workspace_create(MsmWorkspace** out, const MsmInstance* insts, int ninst
     if (nb > ws->max_buckets) ws->max_buckets = (uint32_t)nb;
     if (tasks > ws->max_tasks) ws->max_tasks = (uint32_t)tasks;
     if (tasks * pb > part_bytes) part_bytes = tasks * pb;
-    if (m.W * nseg * pb > seg_bytes) seg_bytes = m.W * nseg * pb;
-    const size_t rb = 2 * (size_t)m.W * ((nseg + 63) / 64) * pb;
+    if ((m.W + 1) * nseg * pb > seg_bytes) seg_bytes = (m.W + 1) * nseg * pb;
+    const size_t rb = 2 * (size_t)(m.W + 1) * ((nseg + 63) / 64) * pb;
     if (rb > red_bytes) red_bytes = rb;
-    if ((size_t)m.W * pb > pin_bytes) pin_bytes = (size_t)m.W * pb;
+    if ((size_t)(m.W + 1) * pb > pin_bytes) pin_bytes = (size_t)(m.W + 1) * pb;
   }
   *out = ws;
   G16_HIP(hipMalloc(&ws->d_cnt, ((size_t)ws->max_buckets + 1) * 4));
@@ -89,6 +89,8 @@ int msm_workspace_create(MsmWorkspace** out, const MsmInstance* insts, int ninst
   G16_HIP(hipMalloc(&ws->d_toff, ((size_t)ws->max_buckets + 1) * 4));
   G16_HIP(hipMalloc(&ws->d_sorted, ((size_t)ws->max_entries + 1) * 4));
   G16_HIP(hipMalloc(&ws->d_task_bucket, ((size_t)ws->max_tasks + 1) * 4));
+  G16_HIP(hipMalloc(&ws->d_tile_a, ((size_t)ws->max_buckets / kScanTile + 2) * 4));
+  G16_HIP(hipMalloc(&ws->d_tile_b, ((size_t)ws->max_buckets / kScanTile + 2) * 4));
   G16_HIP(hipMalloc(&ws->d_partial, part_bytes + 256));
   G16_HIP(hipMalloc(&ws->d_seg, seg_bytes + 256));
   G16_HIP(hipMalloc(&ws->d_red, red_bytes + 256));
@@ -100,7 +102,7 @@ int msm_workspace_create(MsmWorkspace** out, const MsmInstance* insts, int ninst
 
 void msm_workspace_destroy(MsmWorkspace* ws) {
   if (!ws) return;
-  void* ptrs[] = {ws->d_cnt, ws->d_off, ws->d_cursor, ws->d_toff, ws->d_sorted, ws->d_task_bucket,
+  void* ptrs[] = {ws->d_cnt, ws->d_off, ws->d_cursor, ws->d_toff, ws->d_sorted, ws->d_task_bucket, ws->d_tile_a, ws->d_tile_b,
                   ws->d_partial, ws->d_seg, ws->d_red};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);

@@ -110,16 +110,10 @@ static int multiexp_impl(int device, int curve, const uint8_t* bases, const uint
   if (!rc) rc = ds.alloc(n * 32);
   if (!rc && hipMemcpy(ds.p, scalars, n * 32, hipMemcpyHostToDevice) != hipSuccess) { set_error("hipMemcpy failed"); rc = G16_E_HIP; }
   if (!rc && hipStreamCreate(&st) != hipSuccess) { set_error("hipStreamCreate failed"); rc = G16_E_HIP; }
-  std::vector<uint8_t> win((size_t)m.W * sizeof(XYZZ<F>) + 16);
+  std::vector<uint8_t> win((size_t)(m.W + 1) * sizeof(XYZZ<F>) + 16);
   if (!rc) rc = msm_run(m, ws, (const Fr*)ds.p, win.data(), st);
   if (!rc) {
-    xyzz_set_inf(total);
-    for (int j = m.W - 1; j >= 0; j--) {
-      for (int k = 0; k < m.c; k++) xyzz_dbl(total);
-      XYZZ<F> w;
-      memcpy(&w, win.data() + (size_t)j * sizeof(w), sizeof(w));
-      xyzz_add(total, w);
-    }
+    msm_combine_windows<F>(total, win.data(), m.W, m.c);
     Affine<F> r;
     xyzz_to_affine(r, total);
     to_std_bytes<F>(out, r);

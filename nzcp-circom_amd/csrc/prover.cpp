@@ -66,16 +66,6 @@ static const uint32_t kQ[8] = G16_FQ_P;
 static const uint32_t kR[8] = G16_FR_P;
 
 // ------------------------------------------------------------------ host point helpers
-template <class F> static void horner_windows(XYZZ<F>& total, const uint8_t* windows, int W, int c) {
-  xyzz_set_inf(total);
-  for (int j = W - 1; j >= 0; j--) {
-    if (!xyzz_is_inf(total))
-      for (int k = 0; k < c; k++) xyzz_dbl(total);
-    XYZZ<F> w;
-    memcpy(&w, windows + (size_t)j * sizeof(XYZZ<F>), sizeof(w));
-    xyzz_add(total, w);
-  }
-}
 static void g1_out(uint8_t out[64], const G1Affine& p) {  // Montgomery affine -> standard LE bytes
   Fq x = fp_from_mont(p.x), y = fp_from_mont(p.y);
   memcpy(out, x.v, 32);
@@ -293,7 +283,7 @@ static int create_impl(const uint8_t* zkey, size_t len, const g16_opts* opts, g1
   G16_HIP(hipMalloc(&P->d_p, vb));
   size_t wb = 0;
   for (auto& m : P->msm) {
-    const size_t b = (size_t)m.W * msm_point_bytes(m.curve);
+    const size_t b = (size_t)(m.W + 1) * msm_point_bytes(m.curve);
     if (b > wb) wb = b;
   }
   P->winbuf.resize(wb);
@@ -353,7 +343,7 @@ static int run_one_msm(g16_prover* P, int i, const Fr* scalars, XYZZ<F>& out) {
   G16_HIP(hipEventSynchronize(e1));
   (void)hipEventElapsedTime(&P->tm.msm_ms[i], e0, e1);
   P->tm.msm_accum_kernel_ms[i] = msm_last_accum_ms(P->ws);
-  horner_windows<F>(out, P->winbuf.data(), P->msm[i].W, P->msm[i].c);
+  msm_combine_windows<F>(out, P->winbuf.data(), P->msm[i].W, P->msm[i].c);
   return G16_OK;
 }
 
