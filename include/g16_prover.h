@@ -102,6 +102,12 @@ int g16_prove_partial(g16_prover* p, uint32_t slot, uint8_t partial[G16_PARTIAL_
 int g16_prove_finish(g16_prover* p, uint32_t slot, const uint8_t* partials, uint32_t count,
                      const uint8_t r[32], const uint8_t s[32], g16_proof* out, uint8_t* pub);
 
+/* Host-only assembly from gathered partials (no GPU handle needed; reads only the zkey header),
+ * and the shard -> point-range map used by g16_create. */
+int g16_finish_host(const uint8_t* zkey, size_t zkey_len, const uint8_t* partials, uint32_t count,
+                    const uint8_t r[32], const uint8_t s[32], g16_proof* out);
+void g16_shard_range(uint32_t total, int32_t rank, int32_t count, uint32_t* lo, uint32_t* hi);
+
 int g16_get_info(const g16_prover* p, g16_info* out);
 int g16_get_timings(const g16_prover* p, g16_timings* out);
 void g16_destroy(g16_prover* p);

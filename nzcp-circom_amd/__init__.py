@@ -53,7 +53,7 @@ EXPORTS = ["g16_create", "g16_prove", "g16_prove_batch", "g16_stage_witness", "g
            "g16_prove_partial", "g16_prove_finish", "g16_get_info", "g16_get_timings", "g16_destroy",
            "g16_last_error", "g16_fr_fft", "g16_fr_ifft", "g16_fr_batch_mul", "g16_field_op",
            "g16_ec_add", "g16_g1_multiexp", "g16_g2_multiexp", "g16_synth_setup",
-           "g16_synth_witness", "g16_free"]
+           "g16_synth_witness", "g16_free", "g16_finish_host", "g16_shard_range"]
 
 
 def load():
@@ -91,6 +91,9 @@ def load():
                                     C.POINTER(vp), C.POINTER(sz)]
     lib.g16_synth_witness.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint64, C.c_uint64,
                                       C.POINTER(vp), C.POINTER(sz)]
+    lib.g16_finish_host.argtypes = [C.c_char_p, sz, C.c_char_p, C.c_uint32, C.c_char_p, C.c_char_p, C.POINTER(Proof)]
+    lib.g16_shard_range.argtypes = [C.c_uint32, C.c_int32, C.c_int32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
+    lib.g16_shard_range.restype = None
     lib.g16_free.argtypes = [vp]
     lib.g16_free.restype = None
     _lib = lib
@@ -198,6 +201,20 @@ class Prover:
         return {"upload_ms": t.upload_ms, "qap_ms": t.qap_ms, "ntt_ms": t.ntt_ms,
                 "msm_ms": list(t.msm_ms), "tail_ms": t.tail_ms, "total_ms": t.total_ms,
                 "msm_accum_kernel_ms": list(t.msm_accum_kernel_ms)}
+
+
+def finish_host(zkey, partials, r, s):
+    """Assemble a proof from gathered partial-sum blobs on the host (no GPU handle)."""
+    pr = Proof()
+    blob = b"".join(partials)
+    _check(load().g16_finish_host(zkey, len(zkey), blob, len(partials), r, s, C.byref(pr)))
+    return proof_to_obj(pr)
+
+
+def shard_range(total, rank, count):
+    lo, hi = C.c_uint32(), C.c_uint32()
+    load().g16_shard_range(total, rank, count, C.byref(lo), C.byref(hi))
+    return lo.value, hi.value
 
 
 # ------------------------------------------------------------------ operator-level (ffjavascript twins)

@@ -66,6 +66,7 @@ int qap_eval(const QapCsr& q, const Fr* w_std, Fr* a, Fr* b, Fr* cc, hipStream_t
 struct MsmConfig {
   int c = 0;           // window bits (0 = choose from n)
   int task_len = 0;    // max sorted entries per accumulation task (0 = default)
+  bool dense = true;   // scalars uniform in Fr (H) vs NZCP witness mix (~1/3 full-width)
 };
 struct MsmWorkspace;   // opaque, msm.cuh
 // Fixed-base-set MSM instance: bases resident in HBM, infinity points compacted away.

@@ -41,7 +41,9 @@ int msm_instance_create(MsmInstance& m, int curve, const uint8_t* bases_host, ui
   }
   m.n = (uint32_t)src.size();
   if (m.n >= 0x7fffffffu) { set_error("msm: too many bases"); return G16_E_ARG; }
-  m.c = cfg.c ? cfg.c : choose_c(m.n ? m.n : 1);
+  // witness MSMs: only ~1/3 of the scalars are full-width -> size the windows for that
+  const uint32_t n_eff = cfg.dense ? m.n : m.n / 3 + 1;
+  m.c = cfg.c ? cfg.c : choose_c(n_eff ? n_eff : 1);
   if (m.c < 2 || m.c > 16) { set_error("msm: window bits must be in [2,16]"); return G16_E_ARG; }
   m.W = (256 + m.c - 1) / m.c;
   m.nbuckets = 1u << (m.c - 1);

@@ -5,6 +5,8 @@
 // the same five multi-exponentiations and the same blinding equations.
 // There is NO CPU fallback: without a HIP device every compute entry point fails with G16_E_NOGPU.
 #include <fcntl.h>
+#include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 #include <unistd.h>
 
@@ -94,6 +96,11 @@ static int random_scalar(uint32_t out[8]) {  // snarkjs Fr.random() counterpart:
   return G16_OK;
 }
 
+struct KeyPoints {  // the zkey header points the proof tail needs (affine Montgomery)
+  G1Affine alpha1, beta1, delta1;
+  G2Affine beta2, delta2;
+};
+
 struct Partial {  // XYZZ sums of one shard, Montgomery
   G1XYZZ A, B1, C, H;
   G2XYZZ B2;
@@ -111,8 +118,7 @@ struct g16_prover {
   hipStream_t st = nullptr;
   uint32_t nVars = 0, nPublic = 0, N = 0, nCoefs = 0;
   int L = 0;
-  G1Affine alpha1, beta1, delta1;
-  G2Affine beta2, delta2;
+  KeyPoints kp;
   QapCsr csr;
   NttTables ntt;
   MsmInstance msm[5];  // A, B1, B2, C, H
@@ -236,12 +242,12 @@ static int create_impl(const uint8_t* zkey, size_t len, const g16_opts* opts, g1
   }
   P->L = 0;
   while ((1u << P->L) < P->N) P->L++;
-  memcpy(&P->alpha1, h, 64); h += 64;
-  memcpy(&P->beta1, h, 64); h += 64;
-  memcpy(&P->beta2, h, 128); h += 128;
+  memcpy(&P->kp.alpha1, h, 64); h += 64;
+  memcpy(&P->kp.beta1, h, 64); h += 64;
+  memcpy(&P->kp.beta2, h, 128); h += 128;
   h += 128;  // gamma2 (verifier only)
-  memcpy(&P->delta1, h, 64); h += 64;
-  memcpy(&P->delta2, h, 128);
+  memcpy(&P->kp.delta1, h, 64); h += 64;
+  memcpy(&P->kp.delta2, h, 128);
   if ((rc = need_section(f, 4, "zkey", s4))) return rc;
   static const uint32_t ids[5] = {5, 6, 7, 8, 9};
   for (int i = 0; i < 5; i++)
@@ -268,8 +274,14 @@ static int create_impl(const uint8_t* zkey, size_t len, const g16_opts* opts, g1
   const uint32_t totals[5] = {P->nVars, P->nVars, P->nVars, nC, P->N};
   const uint32_t base_off[5] = {0, 0, 0, P->nPublic + 1, 0};
   const int curve[5] = {1, 1, 2, 1, 1};
+  // tuning override: G16_WINDOW_BITS="a,b1,b2,c,h" (0 = auto), G16_TASK_LEN=n
+  int c_over[5] = {0, 0, 0, 0, 0};
+  if (const char* e = getenv("G16_WINDOW_BITS")) sscanf(e, "%d,%d,%d,%d,%d", &c_over[0], &c_over[1], &c_over[2], &c_over[3], &c_over[4]);
+  if (const char* e = getenv("G16_TASK_LEN")) cfg.task_len = atoi(e);
   for (int i = 0; i < 5; i++) {
     uint32_t lo, hi;
+    cfg.c = c_over[i] ? c_over[i] : (opts ? opts->window_bits : 0);
+    cfg.dense = (i == 4);   // H scalars are uniform in Fr; witness scalars are mostly 0/1/small
     shard_range(totals[i], P->shard_rank, P->shard_count, lo, hi);
     const size_t psz = curve[i] == 2 ? 128 : 64;
     if ((rc = msm_instance_create(P->msm[i], curve[i], sb[i].p + (size_t)lo * psz, hi - lo, base_off[i] + lo, cfg)))
@@ -376,8 +388,8 @@ static int device_impl(g16_prover* P, uint32_t slot, Partial& out) {
 }
 
 // Proof assembly on the host: O(1) work, ~1.5k field products.
-static int finish_impl(g16_prover* P, uint32_t slot, const Partial* parts, uint32_t count, const uint8_t* r_in,
-                       const uint8_t* s_in, g16_proof* out, uint8_t* pub) {
+static int finish_impl(const KeyPoints* P, const Partial* parts, uint32_t count, const uint8_t* r_in,
+                       const uint8_t* s_in, g16_proof* out) {
   uint32_t r[8], s[8];
   int rc;
   if (r_in) memcpy(r, r_in, 32); else if ((rc = random_scalar(r))) return rc;
@@ -429,7 +441,6 @@ static int finish_impl(g16_prover* P, uint32_t slot, const Partial* parts, uint3
   g1_out(out->a, a_aff);
   g2_out(out->b, b_aff);
   g1_out(out->c, c_aff);
-  if (pub && P->nPublic) memcpy(pub, P->slot_pub[slot].data(), (size_t)P->nPublic * 32);
   return G16_OK;
 }
 
@@ -473,7 +484,9 @@ int g16_prove_finish(g16_prover* p, uint32_t slot, const uint8_t* partials, uint
   if (slot >= p->slot_pub.size()) { set_error("witness slot not staged"); return G16_E_STATE; }
   std::vector<Partial> parts(count);
   memcpy(parts.data(), partials, (size_t)count * sizeof(Partial));
-  return finish_impl(p, slot, parts.data(), count, r, s, out, pub);
+  int rc = finish_impl(&p->kp, parts.data(), count, r, s, out);
+  if (!rc && pub && p->nPublic) memcpy(pub, p->slot_pub[slot].data(), (size_t)p->nPublic * 32);
+  return rc;
 }
 
 int g16_prove_staged(g16_prover* p, uint32_t slot, const uint8_t r[32], const uint8_t s[32], g16_proof* out,
@@ -484,7 +497,9 @@ int g16_prove_staged(g16_prover* p, uint32_t slot, const uint8_t r[32], const ui
   Partial part;
   int rc = device_impl(p, slot, part);
   if (rc) return rc;
-  return finish_impl(p, slot, &part, 1, r, s, out, pub);
+  rc = finish_impl(&p->kp, &part, 1, r, s, out);
+  if (!rc && pub && p->nPublic) memcpy(pub, p->slot_pub[slot].data(), (size_t)p->nPublic * 32);
+  return rc;
 }
 
 int g16_prove(g16_prover* p, const uint8_t* wtns, size_t wtns_len, const uint8_t r[32], const uint8_t s[32],
@@ -503,6 +518,36 @@ int g16_prove_batch(g16_prover* p, const uint8_t* const* wtns, const size_t* wtn
     if (rc) return rc;
   }
   return G16_OK;
+}
+
+// Host-only proof assembly from gathered partial sums: needs no GPU handle (the assembling rank
+// may hold only the zkey header).  Same arithmetic as g16_prove_finish.
+int g16_finish_host(const uint8_t* zkey, size_t zkey_len, const uint8_t* partials, uint32_t count,
+                    const uint8_t r[32], const uint8_t s[32], g16_proof* out) {
+  if (!zkey || !partials || !count || !out) { set_error("NULL argument"); return G16_E_ARG; }
+  BinFile f;
+  int rc = read_binfile(zkey, zkey_len, "zkey", 2, "zkey", f);
+  if (rc) return rc;
+  Section s1, s2;
+  if ((rc = need_section(f, 1, "zkey", s1))) return rc;
+  if (s1.size < 4 || rd32(s1.p) != 1) { set_error("zkey file is not groth16"); return G16_E_FORMAT; }
+  if ((rc = need_section(f, 2, "zkey", s2))) return rc;
+  if (s2.size < 84 + 576) { set_error("zkey: Invalid File format"); return G16_E_FORMAT; }
+  const uint8_t* h = s2.p + 84;
+  KeyPoints kp;
+  memcpy(&kp.alpha1, h, 64);
+  memcpy(&kp.beta1, h + 64, 64);
+  memcpy(&kp.beta2, h + 128, 128);
+  memcpy(&kp.delta1, h + 384, 64);
+  memcpy(&kp.delta2, h + 448, 128);
+  std::vector<Partial> parts(count);
+  memcpy(parts.data(), partials, (size_t)count * sizeof(Partial));
+  return finish_impl(&kp, parts.data(), count, r, s, out);
+}
+
+// The point range [lo, hi) of a `total`-point base section owned by shard `rank` of `count`.
+void g16_shard_range(uint32_t total, int32_t rank, int32_t count, uint32_t* lo, uint32_t* hi) {
+  shard_range(total, rank, count < 1 ? 1 : count, *lo, *hi);
 }
 
 int g16_get_info(const g16_prover* p, g16_info* o) {
