@@ -38,6 +38,9 @@ struct MsmWorkspace {
   uint32_t* d_tile_a = nullptr;
   uint32_t* d_tile_b = nullptr;
   void* d_partial = nullptr;
+  void* d_bsum = nullptr;         // one XYZZ per bucket after the combine pass
+  uint32_t* d_heavy = nullptr;    // [0] = count, [1..] = bucket ids with more than kLightTasks partials
+  uint32_t max_heavy = 0;
   void* d_seg = nullptr;
   void* d_red = nullptr;
   uint8_t* h_pinned = nullptr;
@@ -262,10 +265,70 @@ __device__ __forceinline__ void msm_mul_small(XYZZ<F>& r, const XYZZ<F>& p, uint
   }
 }
 
+static constexpr uint32_t kLightTasks = 6;   // buckets with more partials take the wavefront path
+
+template <class F> __device__ __forceinline__ XYZZ<F> xyzz_shfl_down(const XYZZ<F>& p, int delta) {
+  XYZZ<F> r;
+  constexpr int NW = sizeof(XYZZ<F>) / 4;
+  const uint32_t* s = reinterpret_cast<const uint32_t*>(&p);
+  uint32_t* d = reinterpret_cast<uint32_t*>(&r);
+#pragma unroll
+  for (int i = 0; i < NW; i++) d[i] = __shfl_down(s[i], delta, 64);
+  return r;
+}
+
+// bsum[b] = sum of the task partials of bucket b (light buckets); heavy buckets are queued.
+template <class F>
+__global__ __launch_bounds__(64) void msm_combine_light_kernel(const XYZZ<F>* __restrict__ partial,
+                                                               const uint32_t* __restrict__ toff, uint32_t nb,
+                                                               XYZZ<F>* __restrict__ bsum,
+                                                               uint32_t* __restrict__ heavy, uint32_t max_heavy) {
+  const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= nb) return;
+  const uint32_t t0 = toff[b], t1 = toff[b + 1];
+  XYZZ<F> acc;
+  xyzz_set_inf(acc);
+  if (t1 - t0 > kLightTasks) {
+    const uint32_t k = atomicAdd(&heavy[0], 1u);
+    if (k < max_heavy) heavy[1 + k] = b;   // cannot overflow: max_heavy >= max_tasks / kLightTasks
+    return;                                // bsum[b] written by the heavy kernel
+  }
+  for (uint32_t t = t0; t < t1; t++) {
+    const XYZZ<F> s = partial[t];
+    xyzz_add(acc, s);
+  }
+  bsum[b] = acc;
+}
+
+// One wavefront per heavy bucket: lanes stride over the partials, then a 6-step shuffle tree.
+template <class F>
+__global__ __launch_bounds__(64) void msm_combine_heavy_kernel(const XYZZ<F>* __restrict__ partial,
+                                                               const uint32_t* __restrict__ toff,
+                                                               XYZZ<F>* __restrict__ bsum,
+                                                               const uint32_t* __restrict__ heavy, uint32_t max_heavy) {
+  uint32_t count = heavy[0];
+  if (count > max_heavy) count = max_heavy;
+  const uint32_t lane = threadIdx.x;
+  for (uint32_t h = blockIdx.x; h < count; h += gridDim.x) {
+    const uint32_t b = heavy[1 + h];
+    const uint32_t t0 = toff[b], t1 = toff[b + 1];
+    XYZZ<F> acc;
+    xyzz_set_inf(acc);
+    for (uint32_t t = t0 + lane; t < t1; t += 64) {
+      const XYZZ<F> s = partial[t];
+      xyzz_add(acc, s);
+    }
+    for (int d = 32; d >= 1; d >>= 1) {
+      const XYZZ<F> q = xyzz_shfl_down(acc, d);
+      xyzz_add(acc, q);
+    }
+    if (lane == 0) bsum[b] = acc;
+  }
+}
+
 // seg[j*nseg + g] = sum_{bi in segment g of window j} (bi+1) * S_bi   (j < W);  j == W: sum S_bi
 template <class F>
-__global__ __launch_bounds__(64) void msm_bucket_reduce_kernel(const XYZZ<F>* __restrict__ partial,
-                                                               const uint32_t* __restrict__ toff, uint32_t B,
+__global__ __launch_bounds__(64) void msm_bucket_reduce_kernel(const XYZZ<F>* __restrict__ bsum, uint32_t B,
                                                                uint32_t nseg, uint32_t W,
                                                                XYZZ<F>* __restrict__ seg) {
   const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
@@ -278,11 +341,8 @@ __global__ __launch_bounds__(64) void msm_bucket_reduce_kernel(const XYZZ<F>* __
   xyzz_set_inf(run);
   xyzz_set_inf(acc);
   for (uint32_t bi = hi; bi-- > lo;) {
-    const uint32_t b = j * B + bi;
-    for (uint32_t t = toff[b], e = toff[b + 1]; t < e; t++) {
-      const XYZZ<F> s = partial[t];
-      xyzz_add(run, s);
-    }
+    const XYZZ<F> s = bsum[(size_t)j * B + bi];
+    xyzz_add(run, s);
     if (!plain) xyzz_add(acc, run);
   }
   if (plain) {
@@ -293,16 +353,6 @@ __global__ __launch_bounds__(64) void msm_bucket_reduce_kernel(const XYZZ<F>* __
     xyzz_add(acc, m);
   }
   seg[tid] = acc;
-}
-
-template <class F> __device__ __forceinline__ XYZZ<F> xyzz_shfl_down(const XYZZ<F>& p, int delta) {
-  XYZZ<F> r;
-  constexpr int NW = sizeof(XYZZ<F>) / 4;
-  const uint32_t* s = reinterpret_cast<const uint32_t*>(&p);
-  uint32_t* d = reinterpret_cast<uint32_t*>(&r);
-#pragma unroll
-  for (int i = 0; i < NW; i++) d[i] = __shfl_down(s[i], delta, 64);
-  return r;
 }
 
 // out[j*nout + blk] = sum of in[j*nin + blk*64 .. +64)
@@ -360,8 +410,13 @@ int msm_run_t(const MsmInstance& m, MsmWorkspace* ws, const Fr* d_scalars, uint8
       (const Affine<F>*)m.d_bases, ws->d_sorted, ws->d_off, ws->d_toff, nb, ws->d_task_bucket, m.task_len,
       (PT*)ws->d_partial);
   G16_HIP(hipEventRecord(ws->ev1, st));
-  msm_bucket_reduce_kernel<F><<<(WT * nseg + 63) / 64, 64, 0, st>>>((const PT*)ws->d_partial, ws->d_toff, B,
-                                                                   nseg, W, (PT*)ws->d_seg);
+  G16_HIP(hipMemsetAsync(ws->d_heavy, 0, 4, st));
+  msm_combine_light_kernel<F><<<(nb + 63) / 64, 64, 0, st>>>((const PT*)ws->d_partial, ws->d_toff, nb,
+                                                             (PT*)ws->d_bsum, ws->d_heavy, ws->max_heavy);
+  msm_combine_heavy_kernel<F><<<1024, 64, 0, st>>>((const PT*)ws->d_partial, ws->d_toff, (PT*)ws->d_bsum,
+                                                   ws->d_heavy, ws->max_heavy);
+  msm_bucket_reduce_kernel<F><<<(WT * nseg + 63) / 64, 64, 0, st>>>((const PT*)ws->d_bsum, B, nseg, W,
+                                                                   (PT*)ws->d_seg);
   // tree: d_seg (nseg per window) -> ... -> 1 per window, ping-pong between d_red halves
   PT* cur = (PT*)ws->d_seg;
   uint32_t cnt = nseg;

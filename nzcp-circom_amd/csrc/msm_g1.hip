@@ -47,7 +47,14 @@ int msm_instance_create(MsmInstance& m, int curve, const uint8_t* bases_host, ui
   if (m.c < 2 || m.c > 16) { set_error("msm: window bits must be in [2,16]"); return G16_E_ARG; }
   m.W = (256 + m.c - 1) / m.c;
   m.nbuckets = 1u << (m.c - 1);
-  m.task_len = cfg.task_len ? (uint32_t)cfg.task_len : 256u;
+  // Task length: enough tasks to fill ~256k lanes (256 CUs x 4 SIMDs x 4 waves x 64), within [16, 256].
+  if (cfg.task_len) {
+    m.task_len = (uint32_t)cfg.task_len;
+  } else {
+    const uint64_t entries = (uint64_t)n_eff * m.W;
+    uint64_t t = entries / 262144;
+    m.task_len = (uint32_t)(t < 16 ? 16 : (t > 256 ? 256 : t));
+  }
   if (m.n) {
     G16_HIP(hipMalloc(&m.d_bases, packed.size()));
     G16_HIP(hipMalloc(&m.d_src, (size_t)m.n * 4));
@@ -67,7 +74,7 @@ void msm_instance_destroy(MsmInstance& m) {
 
 int msm_workspace_create(MsmWorkspace** out, const MsmInstance* insts, int ninst) {
   MsmWorkspace* ws = new MsmWorkspace();
-  size_t part_bytes = 0, seg_bytes = 0, red_bytes = 0, pin_bytes = 0;
+  size_t part_bytes = 0, seg_bytes = 0, red_bytes = 0, pin_bytes = 0, bsum_bytes = 0;
   for (int i = 0; i < ninst; i++) {
     const MsmInstance& m = insts[i];
     const uint64_t nb = (uint64_t)(m.W + 1) * m.nbuckets;   // + the ones window
@@ -79,6 +86,7 @@ int msm_workspace_create(MsmWorkspace** out, const MsmInstance* insts, int ninst
     if (nb > ws->max_buckets) ws->max_buckets = (uint32_t)nb;
     if (tasks > ws->max_tasks) ws->max_tasks = (uint32_t)tasks;
     if (tasks * pb > part_bytes) part_bytes = tasks * pb;
+    if (nb * pb > bsum_bytes) bsum_bytes = nb * pb;
     if ((m.W + 1) * nseg * pb > seg_bytes) seg_bytes = (m.W + 1) * nseg * pb;
     const size_t rb = 2 * (size_t)(m.W + 1) * ((nseg + 63) / 64) * pb;
     if (rb > red_bytes) red_bytes = rb;
@@ -94,6 +102,9 @@ int msm_workspace_create(MsmWorkspace** out, const MsmInstance* insts, int ninst
   G16_HIP(hipMalloc(&ws->d_tile_a, ((size_t)ws->max_buckets / kScanTile + 2) * 4));
   G16_HIP(hipMalloc(&ws->d_tile_b, ((size_t)ws->max_buckets / kScanTile + 2) * 4));
   G16_HIP(hipMalloc(&ws->d_partial, part_bytes + 256));
+  G16_HIP(hipMalloc(&ws->d_bsum, bsum_bytes + 256));
+  ws->max_heavy = ws->max_tasks / kLightTasks + 16;
+  G16_HIP(hipMalloc(&ws->d_heavy, ((size_t)ws->max_heavy + 2) * 4));
   G16_HIP(hipMalloc(&ws->d_seg, seg_bytes + 256));
   G16_HIP(hipMalloc(&ws->d_red, red_bytes + 256));
   G16_HIP(hipHostMalloc((void**)&ws->h_pinned, pin_bytes + 256));
@@ -105,7 +116,7 @@ int msm_workspace_create(MsmWorkspace** out, const MsmInstance* insts, int ninst
 void msm_workspace_destroy(MsmWorkspace* ws) {
   if (!ws) return;
   void* ptrs[] = {ws->d_cnt, ws->d_off, ws->d_cursor, ws->d_toff, ws->d_sorted, ws->d_task_bucket, ws->d_tile_a, ws->d_tile_b,
-                  ws->d_partial, ws->d_seg, ws->d_red};
+                  ws->d_partial, ws->d_seg, ws->d_red, ws->d_bsum, ws->d_heavy};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   if (ws->h_pinned) (void)hipHostFree(ws->h_pinned);
