@@ -92,6 +92,10 @@ void msm_workspace_destroy(MsmWorkspace* ws);
 float msm_last_accum_ms(const MsmWorkspace* ws);
 int msm_run(const MsmInstance& m, MsmWorkspace* ws, const Fr* d_scalars, uint8_t* out_windows,
             hipStream_t st);
+// The same split in two so several MSMs can be in flight on different streams: msm_launch only
+// enqueues (each MSM needs its own workspace), msm_collect waits for that stream and copies out.
+int msm_launch(const MsmInstance& m, MsmWorkspace* ws, const Fr* d_scalars, hipStream_t st);
+int msm_collect(MsmWorkspace* ws, uint8_t* out_windows, hipStream_t st);
 
 // total = sum_j 2^(c j) * windows[j]  (Horner, c doublings per window) + windows[W] (ones window)
 template <class F> inline void msm_combine_windows(XYZZ<F>& total, const uint8_t* windows, int W, int c) {

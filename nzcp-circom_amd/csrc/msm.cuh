@@ -46,6 +46,8 @@ struct MsmWorkspace {
   uint8_t* h_pinned = nullptr;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;  // around the bucket-accumulate kernel
   float last_accum_ms = 0.f;
+  uint32_t launched_n = 0;
+  size_t out_bytes = 0;
 };
 
 struct U256 { uint32_t v[8]; };
@@ -380,16 +382,15 @@ inline void msm_make_K(int c, int W, U256& K) {
   }
 }
 
+// Enqueues the whole MSM on `st` (no host synchronisation); results land in ws->h_pinned.
 template <class F>
-int msm_run_t(const MsmInstance& m, MsmWorkspace* ws, const Fr* d_scalars, uint8_t* out_windows,
-              hipStream_t st) {
+int msm_launch_t(const MsmInstance& m, MsmWorkspace* ws, const Fr* d_scalars, hipStream_t st) {
   using PT = XYZZ<F>;
   const uint32_t W = (uint32_t)m.W, B = m.nbuckets, WT = W + 1, nb = WT * B;  // + the ones window
   ws->last_accum_ms = 0.f;
-  if (m.n == 0) {
-    memset(out_windows, 0, (size_t)WT * sizeof(PT));
-    return G16_OK;
-  }
+  ws->launched_n = m.n;
+  ws->out_bytes = (size_t)WT * sizeof(PT);
+  if (m.n == 0) return G16_OK;
   const uint32_t nseg = (B + kSegLen - 1) / kSegLen;
   U256 K;
   msm_make_K(m.c, m.W, K);
@@ -431,9 +432,6 @@ int msm_run_t(const MsmInstance& m, MsmWorkspace* ws, const Fr* d_scalars, uint8
   }
   G16_HIP(hipGetLastError());
   G16_HIP(hipMemcpyAsync(ws->h_pinned, cur, (size_t)WT * sizeof(PT), hipMemcpyDeviceToHost, st));
-  G16_HIP(hipStreamSynchronize(st));
-  (void)hipEventElapsedTime(&ws->last_accum_ms, ws->ev0, ws->ev1);
-  memcpy(out_windows, ws->h_pinned, (size_t)WT * sizeof(PT));
   return G16_OK;
 }
 

@@ -125,14 +125,31 @@ void msm_workspace_destroy(MsmWorkspace* ws) {
   delete ws;
 }
 
-int msm_run_g2(const MsmInstance& m, MsmWorkspace* ws, const Fr* d_scalars, uint8_t* out, hipStream_t st);
+int msm_launch_g2(const MsmInstance& m, MsmWorkspace* ws, const Fr* d_scalars, hipStream_t st);
 
 float msm_last_accum_ms(const MsmWorkspace* ws) { return ws->last_accum_ms; }
 
+int msm_launch(const MsmInstance& m, MsmWorkspace* ws, const Fr* d_scalars, hipStream_t st) {
+  if (m.curve == 2) return msm_launch_g2(m, ws, d_scalars, st);
+  return msm_launch_t<FqOps>(m, ws, d_scalars, st);
+}
+
+int msm_collect(MsmWorkspace* ws, uint8_t* out_windows, hipStream_t st) {
+  if (ws->launched_n == 0) {
+    memset(out_windows, 0, ws->out_bytes);
+    return G16_OK;
+  }
+  G16_HIP(hipStreamSynchronize(st));
+  (void)hipEventElapsedTime(&ws->last_accum_ms, ws->ev0, ws->ev1);
+  memcpy(out_windows, ws->h_pinned, ws->out_bytes);
+  return G16_OK;
+}
+
 int msm_run(const MsmInstance& m, MsmWorkspace* ws, const Fr* d_scalars, uint8_t* out_windows,
             hipStream_t st) {
-  if (m.curve == 2) return msm_run_g2(m, ws, d_scalars, out_windows, st);
-  return msm_run_t<FqOps>(m, ws, d_scalars, out_windows, st);
+  int rc = msm_launch(m, ws, d_scalars, st);
+  if (rc) return rc;
+  return msm_collect(ws, out_windows, st);
 }
 
 }  // namespace g16

@@ -4,7 +4,7 @@
 #include "msm.cuh"
 
 namespace g16 {
-int msm_run_g2(const MsmInstance& m, MsmWorkspace* ws, const Fr* d_scalars, uint8_t* out, hipStream_t st) {
-  return msm_run_t<Fq2Ops>(m, ws, d_scalars, out, st);
+int msm_launch_g2(const MsmInstance& m, MsmWorkspace* ws, const Fr* d_scalars, hipStream_t st) {
+  return msm_launch_t<Fq2Ops>(m, ws, d_scalars, st);
 }
 }  // namespace g16

@@ -122,7 +122,9 @@ struct g16_prover {
   QapCsr csr;
   NttTables ntt;
   MsmInstance msm[5];  // A, B1, B2, C, H
-  MsmWorkspace* ws = nullptr;
+  MsmWorkspace* ws[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};  // one per MSM: all five run concurrently
+  hipStream_t mst[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};  // A, B1, B2, C on their own streams; H on `st`
+  hipEvent_t mev[5][2] = {};
   Fr *d_a = nullptr, *d_b = nullptr, *d_c = nullptr, *d_p = nullptr;
   std::vector<Fr*> slot_dev;
   std::vector<std::vector<uint8_t>> slot_pub;
@@ -143,7 +145,9 @@ struct g16_prover {
     }
     ntt_tables_destroy(ntt);
     for (auto& m : msm) msm_instance_destroy(m);
-    msm_workspace_destroy(ws);
+    for (auto& w : ws) msm_workspace_destroy(w);
+    for (int i = 0; i < 4; i++) if (mst[i]) (void)hipStreamDestroy(mst[i]);
+    for (auto& e : mev) { if (e[0]) (void)hipEventDestroy(e[0]); if (e[1]) (void)hipEventDestroy(e[1]); }
     for (auto& e : ev) if (e) (void)hipEventDestroy(e);
     if (st) (void)hipStreamDestroy(st);
   }
@@ -287,7 +291,13 @@ static int create_impl(const uint8_t* zkey, size_t len, const g16_opts* opts, g1
     if ((rc = msm_instance_create(P->msm[i], curve[i], sb[i].p + (size_t)lo * psz, hi - lo, base_off[i] + lo, cfg)))
       return rc;
   }
-  if ((rc = msm_workspace_create(&P->ws, P->msm, 5))) return rc;
+  for (int i = 0; i < 5; i++) {
+    if ((rc = msm_workspace_create(&P->ws[i], &P->msm[i], 1))) return rc;
+    if (i < 4) G16_HIP(hipStreamCreateWithFlags(&P->mst[i], hipStreamNonBlocking));
+    else P->mst[4] = P->st;
+    G16_HIP(hipEventCreate(&P->mev[i][0]));
+    G16_HIP(hipEventCreate(&P->mev[i][1]));
+  }
   const size_t vb = (size_t)P->N * sizeof(Fr);
   G16_HIP(hipMalloc(&P->d_a, vb));
   G16_HIP(hipMalloc(&P->d_b, vb));
@@ -346,26 +356,31 @@ static int stage_impl(g16_prover* P, uint32_t slot, const uint8_t* wtns, size_t 
 }
 
 template <class F>
-static int run_one_msm(g16_prover* P, int i, const Fr* scalars, XYZZ<F>& out) {
-  hipEvent_t e0 = P->ev[6], e1 = P->ev[7];
-  G16_HIP(hipEventRecord(e0, P->st));
-  int rc = msm_run(P->msm[i], P->ws, scalars, P->winbuf.data(), P->st);
+static int collect_one_msm(g16_prover* P, int i, XYZZ<F>& out) {
+  int rc = msm_collect(P->ws[i], P->winbuf.data(), P->mst[i]);
   if (rc) return rc;
-  G16_HIP(hipEventRecord(e1, P->st));
-  G16_HIP(hipEventSynchronize(e1));
-  (void)hipEventElapsedTime(&P->tm.msm_ms[i], e0, e1);
-  P->tm.msm_accum_kernel_ms[i] = msm_last_accum_ms(P->ws);
+  (void)hipEventElapsedTime(&P->tm.msm_ms[i], P->mev[i][0], P->mev[i][1]);
+  P->tm.msm_accum_kernel_ms[i] = msm_last_accum_ms(P->ws[i]);
   msm_combine_windows<F>(out, P->winbuf.data(), P->msm[i].W, P->msm[i].c);
   return G16_OK;
 }
 
-// The device pipeline of one proof on a staged witness: QAP -> NTTs -> join -> 5 MSMs.
+// The device pipeline of one proof on a staged witness.  The four witness MSMs (A, B1, B2, C) do
+// not depend on the H polynomial, so they are enqueued on their own streams first and overlap with
+// QAP -> NTTs -> join -> H-MSM on the main stream; the host folds each MSM's window sums while the
+// later ones are still running.
 static int device_impl(g16_prover* P, uint32_t slot, Partial& out) {
   if (slot >= P->slot_dev.size() || !P->slot_dev[slot]) { set_error("witness slot not staged"); return G16_E_STATE; }
   G16_HIP(hipSetDevice(P->device));
   const Fr* d_w = P->slot_dev[slot];
   int rc;
   G16_HIP(hipEventRecord(P->ev[2], P->st));
+  for (int i = 0; i < 4; i++) {
+    G16_HIP(hipStreamWaitEvent(P->mst[i], P->ev[2], 0));
+    G16_HIP(hipEventRecord(P->mev[i][0], P->mst[i]));
+    if ((rc = msm_launch(P->msm[i], P->ws[i], d_w, P->mst[i]))) return rc;
+    G16_HIP(hipEventRecord(P->mev[i][1], P->mst[i]));
+  }
   if ((rc = qap_eval(P->csr, d_w, P->d_a, P->d_b, P->d_c, P->st))) return rc;
   G16_HIP(hipEventRecord(P->ev[3], P->st));
   Fr* vecs[3] = {P->d_a, P->d_b, P->d_c};
@@ -374,11 +389,14 @@ static int device_impl(g16_prover* P, uint32_t slot, Partial& out) {
   if ((rc = ntt_dit_forward(P->ntt, vecs, 3, P->st))) return rc;
   if ((rc = ntt_join_abc(P->d_a, P->d_b, P->d_c, P->d_p, P->N, P->st))) return rc;
   G16_HIP(hipEventRecord(P->ev[4], P->st));
-  if ((rc = run_one_msm<FqOps>(P, 0, d_w, out.A))) return rc;
-  if ((rc = run_one_msm<FqOps>(P, 1, d_w, out.B1))) return rc;
-  if ((rc = run_one_msm<Fq2Ops>(P, 2, d_w, out.B2))) return rc;
-  if ((rc = run_one_msm<FqOps>(P, 3, d_w, out.C))) return rc;
-  if ((rc = run_one_msm<FqOps>(P, 4, P->d_p, out.H))) return rc;
+  G16_HIP(hipEventRecord(P->mev[4][0], P->st));
+  if ((rc = msm_launch(P->msm[4], P->ws[4], P->d_p, P->st))) return rc;
+  G16_HIP(hipEventRecord(P->mev[4][1], P->st));
+  if ((rc = collect_one_msm<FqOps>(P, 0, out.A))) return rc;
+  if ((rc = collect_one_msm<FqOps>(P, 1, out.B1))) return rc;
+  if ((rc = collect_one_msm<Fq2Ops>(P, 2, out.B2))) return rc;
+  if ((rc = collect_one_msm<FqOps>(P, 3, out.C))) return rc;
+  if ((rc = collect_one_msm<FqOps>(P, 4, out.H))) return rc;
   G16_HIP(hipEventRecord(P->ev[5], P->st));
   G16_HIP(hipEventSynchronize(P->ev[5]));
   (void)hipEventElapsedTime(&P->tm.qap_ms, P->ev[2], P->ev[3]);
