@@ -37,6 +37,9 @@ struct MsmWorkspace {
   uint32_t* d_task_bucket = nullptr;
   uint32_t* d_tile_a = nullptr;
   uint32_t* d_tile_b = nullptr;
+  uint32_t* d_dig = nullptr;      // [(W+1)][n] digit codes (window-major)
+  uint32_t* d_hist = nullptr;     // [(W+1)][chunks][B] per-workgroup histograms -> start offsets
+  uint32_t chunks = 1;
   void* d_partial = nullptr;
   void* d_bsum = nullptr;         // one XYZZ per bucket after the combine pass
   uint32_t* d_heavy = nullptr;    // [0] = count, [1..] = bucket ids with more than kLightTasks partials
@@ -89,45 +92,78 @@ __device__ __forceinline__ uint32_t msm_key(const uint32_t s[8], int j, int c, i
   return mag == 0 ? 0xffffffffu : (uint32_t)j * B + (mag - 1);
 }
 
-static __global__ __launch_bounds__(256) void msm_count_kernel(const Fr* __restrict__ scalars,
-                                                        const uint32_t* __restrict__ src, uint32_t n,
-                                                        int c, int W, U256 K, uint32_t* __restrict__ cnt) {
+// Digit codes, window-major: dig[j*n + i] = bucket (|digit|-1) | sign<<31, or kSkip.  Row W is the
+// "ones" pseudo-window: scalars equal to 1 are spread over its buckets by point index.
+static constexpr uint32_t kSkip = 0x7fffffffu;
+
+static __global__ __launch_bounds__(256) void msm_digits_kernel(const Fr* __restrict__ scalars,
+                                                         const uint32_t* __restrict__ src, uint32_t n,
+                                                         int c, int W, U256 K, uint32_t* __restrict__ dig) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   uint32_t s[8];
   const bool one = msm_load_scalar(scalars, src, i, K, s);
   const uint32_t B = 1u << (c - 1);
-  if (one) {  // the "ones" pseudo-window: unweighted buckets, spread by point index
-    atomicAdd(&cnt[(uint32_t)W * B + (i & (B - 1))], 1u);
-    return;
-  }
   for (int j = 0; j < W; j++) {
     uint32_t neg;
     const uint32_t key = msm_key(s, j, c, W, B, neg);
-    if (key != 0xffffffffu) atomicAdd(&cnt[key], 1u);
+    dig[(size_t)j * n + i] = (one || key == 0xffffffffu) ? kSkip : ((key - (uint32_t)j * B) | (neg << 31));
+  }
+  dig[(size_t)W * n + i] = one ? (i & (B - 1)) : kSkip;
+}
+
+// Counting sort without global atomics: workgroup (window j, chunk) histograms its slice of row j
+// in LDS (MODE 0, writes hist[j][chunk][*]) and later scatters it with LDS cursors preloaded with
+// the exclusive start offsets (MODE 1).
+template <int MODE>
+static __global__ __launch_bounds__(1024) void msm_sort_kernel(const uint32_t* __restrict__ dig, uint32_t n,
+                                                        uint32_t B, uint32_t chunks, uint32_t per,
+                                                        uint32_t* __restrict__ hist,
+                                                        uint32_t* __restrict__ sorted) {
+  extern __shared__ uint32_t lds[];
+  const uint32_t j = blockIdx.x / chunks, chunk = blockIdx.x % chunks;
+  uint32_t* __restrict__ h = hist + ((size_t)j * chunks + chunk) * B;
+  for (uint32_t b = threadIdx.x; b < B; b += 1024) lds[b] = MODE ? h[b] : 0u;
+  __syncthreads();
+  const uint32_t lo = chunk * per;
+  const uint32_t hi = (lo + per < n) ? lo + per : n;
+  const uint32_t* __restrict__ row = dig + (size_t)j * n;
+  for (uint32_t i = lo + threadIdx.x; i < hi; i += 1024) {
+    const uint32_t d = row[i];
+    if (d == kSkip) continue;
+    const uint32_t pos = atomicAdd(&lds[d & 0x7fffffffu], 1u);
+    if (MODE) sorted[pos] = i | (d & 0x80000000u);
+  }
+  if (!MODE) {
+    __syncthreads();
+    for (uint32_t b = threadIdx.x; b < B; b += 1024) h[b] = lds[b];
   }
 }
 
-static __global__ __launch_bounds__(256) void msm_scatter_kernel(const Fr* __restrict__ scalars,
-                                                          const uint32_t* __restrict__ src, uint32_t n,
-                                                          int c, int W, U256 K, uint32_t* __restrict__ cursor,
-                                                          uint32_t* __restrict__ sorted) {
-  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  uint32_t s[8];
-  const bool one = msm_load_scalar(scalars, src, i, K, s);
-  const uint32_t B = 1u << (c - 1);
-  if (one) {
-    sorted[atomicAdd(&cursor[(uint32_t)W * B + (i & (B - 1))], 1u)] = i;
-    return;
-  }
-  for (int j = 0; j < W; j++) {
-    uint32_t neg;
-    const uint32_t key = msm_key(s, j, c, W, B, neg);
-    if (key != 0xffffffffu) {
-      const uint32_t pos = atomicAdd(&cursor[key], 1u);
-      sorted[pos] = i | (neg << 31);
-    }
+// cnt[key] = sum over chunks of hist[j][chunk][b]
+static __global__ __launch_bounds__(256) void msm_hist_sum_kernel(const uint32_t* __restrict__ hist, uint32_t nb,
+                                                           uint32_t B, uint32_t chunks,
+                                                           uint32_t* __restrict__ cnt) {
+  const uint32_t key = blockIdx.x * blockDim.x + threadIdx.x;
+  if (key >= nb) return;
+  const uint32_t j = key / B, b = key % B;
+  uint32_t s = 0;
+  for (uint32_t k = 0; k < chunks; k++) s += hist[((size_t)j * chunks + k) * B + b];
+  cnt[key] = s;
+}
+// hist[j][chunk][b] <- off[key] + sum_{chunk' < chunk} hist[j][chunk'][b]
+static __global__ __launch_bounds__(256) void msm_hist_start_kernel(uint32_t* __restrict__ hist, uint32_t nb,
+                                                             uint32_t B, uint32_t chunks,
+                                                             const uint32_t* __restrict__ off) {
+  const uint32_t key = blockIdx.x * blockDim.x + threadIdx.x;
+  if (key >= nb) return;
+  const uint32_t j = key / B, b = key % B;
+  uint32_t run = off[key];
+  for (uint32_t k = 0; k < chunks; k++) {
+    uint32_t* p = &hist[((size_t)j * chunks + k) * B + b];
+    const uint32_t v = *p;
+    *p = run;
+    run += v;
   }
 }
 
@@ -394,15 +430,27 @@ int msm_launch_t(const MsmInstance& m, MsmWorkspace* ws, const Fr* d_scalars, hi
   const uint32_t nseg = (B + kSegLen - 1) / kSegLen;
   U256 K;
   msm_make_K(m.c, m.W, K);
-  G16_HIP(hipMemsetAsync(ws->d_cnt, 0, (size_t)(nb + 1) * 4, st));
   const uint32_t nblk = (m.n + 255) / 256;
-  msm_count_kernel<<<nblk, 256, 0, st>>>(d_scalars, m.d_src, m.n, m.c, m.W, K, ws->d_cnt);
+  const uint32_t chunks = ws->chunks, per = (m.n + chunks - 1) / chunks;
+  const size_t lds_bytes = (size_t)B * 4;
+  {
+    static bool attr_done = false;   // > 64 KiB of dynamic LDS needs the opt-in (c = 16: 128 KiB histogram)
+    if (!attr_done) {
+      G16_HIP(hipFuncSetAttribute((const void*)msm_sort_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+      G16_HIP(hipFuncSetAttribute((const void*)msm_sort_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+      attr_done = true;
+    }
+  }
+  msm_digits_kernel<<<nblk, 256, 0, st>>>(d_scalars, m.d_src, m.n, m.c, m.W, K, ws->d_dig);
+  msm_sort_kernel<0><<<WT * chunks, 1024, lds_bytes, st>>>(ws->d_dig, m.n, B, chunks, per, ws->d_hist, nullptr);
+  msm_hist_sum_kernel<<<(nb + 255) / 256, 256, 0, st>>>(ws->d_hist, nb, B, chunks, ws->d_cnt);
   const uint32_t ntiles = (nb + kScanTile - 1) / kScanTile;
   msm_scan_tiles_kernel<<<ntiles, 256, 0, st>>>(ws->d_cnt, nb, m.task_len, ws->d_tile_a, ws->d_tile_b);
   msm_scan_top_kernel<<<1, 1024, 0, st>>>(ws->d_tile_a, ws->d_tile_b, ntiles, ws->d_off + nb, ws->d_toff + nb);
   msm_scan_apply_kernel<<<ntiles, 256, 0, st>>>(ws->d_cnt, nb, m.task_len, ws->d_tile_a, ws->d_tile_b, ws->d_off,
                                                 ws->d_cursor, ws->d_toff);
-  msm_scatter_kernel<<<nblk, 256, 0, st>>>(d_scalars, m.d_src, m.n, m.c, m.W, K, ws->d_cursor, ws->d_sorted);
+  msm_hist_start_kernel<<<(nb + 255) / 256, 256, 0, st>>>(ws->d_hist, nb, B, chunks, ws->d_off);
+  msm_sort_kernel<1><<<WT * chunks, 1024, lds_bytes, st>>>(ws->d_dig, m.n, B, chunks, per, ws->d_hist, ws->d_sorted);
   msm_task_fill_kernel<<<(nb + 255) / 256, 256, 0, st>>>(ws->d_toff, nb, ws->d_task_bucket);
   // upper bound on tasks: every non-empty bucket has <= 1 short task + entries/task_len full ones
   const uint64_t max_tasks = (uint64_t)nb + ((uint64_t)m.n * W) / m.task_len;  // ones: <= n entries, covered

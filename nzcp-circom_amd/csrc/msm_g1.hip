@@ -93,6 +93,24 @@ int msm_workspace_create(MsmWorkspace** out, const MsmInstance* insts, int ninst
     if ((size_t)(m.W + 1) * pb > pin_bytes) pin_bytes = (size_t)(m.W + 1) * pb;
   }
   *out = ws;
+  // sort geometry: ~4 workgroups of 1024 threads per CU when the LDS histogram allows it
+  size_t dig_words = 0, hist_words = 0;
+  for (int i = 0; i < ninst; i++) {
+    const MsmInstance& m = insts[i];
+    const uint32_t WT = (uint32_t)m.W + 1;
+    const size_t lds = (size_t)m.nbuckets * 4;
+    uint32_t per_cu = (uint32_t)(160 * 1024 / (lds ? lds : 1));
+    if (per_cu > 2) per_cu = 2;        // 1024-thread workgroups: at most 2 per CU
+    if (per_cu < 1) per_cu = 1;
+    uint32_t chunks = (256 * per_cu + WT - 1) / WT;
+    const uint32_t max_chunks = m.n / 4096 + 1;
+    if (chunks > max_chunks) chunks = max_chunks;
+    if (chunks > ws->chunks) ws->chunks = chunks;
+    if ((size_t)WT * m.n > dig_words) dig_words = (size_t)WT * m.n;
+    if ((size_t)WT * chunks * m.nbuckets > hist_words) hist_words = (size_t)WT * chunks * m.nbuckets;
+  }
+  G16_HIP(hipMalloc(&ws->d_dig, (dig_words + 4) * 4));
+  G16_HIP(hipMalloc(&ws->d_hist, (hist_words + 4) * 4));
   G16_HIP(hipMalloc(&ws->d_cnt, ((size_t)ws->max_buckets + 1) * 4));
   G16_HIP(hipMalloc(&ws->d_off, ((size_t)ws->max_buckets + 1) * 4));
   G16_HIP(hipMalloc(&ws->d_cursor, ((size_t)ws->max_buckets + 1) * 4));
@@ -116,7 +134,7 @@ int msm_workspace_create(MsmWorkspace** out, const MsmInstance* insts, int ninst
 void msm_workspace_destroy(MsmWorkspace* ws) {
   if (!ws) return;
   void* ptrs[] = {ws->d_cnt, ws->d_off, ws->d_cursor, ws->d_toff, ws->d_sorted, ws->d_task_bucket, ws->d_tile_a, ws->d_tile_b,
-                  ws->d_partial, ws->d_seg, ws->d_red, ws->d_bsum, ws->d_heavy};
+                  ws->d_partial, ws->d_seg, ws->d_red, ws->d_bsum, ws->d_heavy, ws->d_dig, ws->d_hist};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   if (ws->h_pinned) (void)hipHostFree(ws->h_pinned);
