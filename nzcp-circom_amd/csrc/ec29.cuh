@@ -1,0 +1,124 @@
+// XYZZ point arithmetic over the lazy 9 x 29-bit field (fq29.cuh) -- what the MSM kernels run.
+// Same formulas as ec.cuh (madd-2008-s, add-2008-s, dbl-2008-s-1, mdbl-2008-s-1); the only
+// difference is that every subtraction names the multiple of p that covers its subtrahend.
+// The K constants and the resulting coordinate bounds (X < 5.4p, Y < 3.5p, ZZ/ZZZ < 1.1p for both
+// G1 and G2; every product input < 16p) come from tools/f29_bounds.py and are asserted at run time
+// by the host differential test (tests/native/f29_test.cpp, built with -DG16_F29_CHECK).
+#pragma once
+#include "ec.cuh"
+#include "fq29.cuh"
+
+namespace g16 {
+
+using G1Affine29 = Affine<Fq29Ops>;
+using G2Affine29 = Affine<Fq2x29Ops>;
+using G1XYZZ29 = XYZZ<Fq29Ops>;
+using G2XYZZ29 = XYZZ<Fq2x29Ops>;
+
+template <class F> G16_HD bool x29_is_inf(const XYZZ<F>& p) { return F::is_literal_zero(p.zz); }
+template <class F> G16_HD void x29_set_inf(XYZZ<F>& p) {
+  p.x = F::zero(); p.y = F::zero(); p.zz = F::zero(); p.zzz = F::zero();
+}
+// x == 0 (mod p) for a difference below 8p: cheap low-limb filter, exact test only on a hit
+template <class F> G16_HD bool x29_diff_is_zero(const typename F::T& d) {
+  if (!F::template maybe_zero<7>(d)) return false;
+  return F::is_zero(d);
+}
+
+// 2*P for affine P (coordinates below 2p)
+template <class F> G16_HD void x29_dbl_affine(XYZZ<F>& r, const Affine<F>& p) {
+  using T = typename F::T;
+  const T U = F::add(p.y, p.y);
+  const T V = F::sqr(U);
+  const T W = F::mul(U, V);
+  const T S = F::mul(p.x, V);
+  const T X2 = F::sqr(p.x);
+  const T M = F::add(F::add(X2, X2), X2);
+  r.x = F::template sub<3>(F::sqr(M), F::add(S, S));
+  r.y = F::template sub<2>(F::mul(M, F::template sub<5>(S, r.x)), F::mul(W, p.y));
+  r.zz = V;
+  r.zzz = W;
+}
+
+template <class F> G16_HD void x29_dbl(XYZZ<F>& p) {
+  using T = typename F::T;
+  if (x29_is_inf(p)) return;
+  const T U = F::add(p.y, p.y);
+  const T V = F::sqr(U);
+  const T W = F::mul(U, V);
+  const T S = F::mul(p.x, V);
+  const T X2 = F::sqr(p.x);
+  const T M = F::add(F::add(X2, X2), X2);
+  const T X3 = F::template sub<3>(F::sqr(M), F::add(S, S));
+  p.y = F::template sub<2>(F::mul(M, F::template sub<5>(S, X3)), F::mul(W, p.y));
+  p.x = X3;
+  p.zz = F::mul(V, p.zz);
+  p.zzz = F::mul(W, p.zzz);
+}
+
+// acc <- acc + q, q affine (coordinates below 2p), not infinity
+template <class F> G16_HD void x29_madd(XYZZ<F>& acc, const Affine<F>& q) {
+  using T = typename F::T;
+  if (x29_is_inf(acc)) {
+    acc.x = q.x; acc.y = q.y; acc.zz = F::one(); acc.zzz = F::one();
+    return;
+  }
+  const T U2 = F::mul(q.x, acc.zz);
+  const T S2 = F::mul(q.y, acc.zzz);
+  const T P = F::template sub<6>(U2, acc.x);
+  const T R = F::template sub<4>(S2, acc.y);
+  if (x29_diff_is_zero<F>(P)) {
+    if (F::is_zero(R)) x29_dbl_affine(acc, q);
+    else x29_set_inf(acc);
+    return;
+  }
+  const T PP = F::sqr(P);
+  const T PPP = F::mul(P, PP);
+  const T Qv = F::mul(acc.x, PP);
+  const T X3 = F::template sub<4>(F::sqr(R), F::add(PPP, F::add(Qv, Qv)));
+  acc.y = F::template sub<2>(F::mul(R, F::template sub<6>(Qv, X3)), F::mul(acc.y, PPP));
+  acc.x = X3;
+  acc.zz = F::mul(acc.zz, PP);
+  acc.zzz = F::mul(acc.zzz, PPP);
+}
+
+// acc <- acc + q, both XYZZ
+template <class F> G16_HD void x29_add(XYZZ<F>& acc, const XYZZ<F>& q) {
+  using T = typename F::T;
+  if (x29_is_inf(q)) return;
+  if (x29_is_inf(acc)) { acc = q; return; }
+  const T U1 = F::mul(acc.x, q.zz);
+  const T U2 = F::mul(q.x, acc.zz);
+  const T S1 = F::mul(acc.y, q.zzz);
+  const T S2 = F::mul(q.y, acc.zzz);
+  const T P = F::template sub<2>(U2, U1);
+  const T R = F::template sub<2>(S2, S1);
+  if (x29_diff_is_zero<F>(P)) {
+    if (F::is_zero(R)) x29_dbl(acc);
+    else x29_set_inf(acc);
+    return;
+  }
+  const T PP = F::sqr(P);
+  const T PPP = F::mul(P, PP);
+  const T Qv = F::mul(U1, PP);
+  const T X3 = F::template sub<4>(F::sqr(R), F::add(PPP, F::add(Qv, Qv)));
+  acc.y = F::template sub<2>(F::mul(R, F::template sub<6>(Qv, X3)), F::mul(S1, PPP));
+  acc.x = X3;
+  acc.zz = F::mul(F::mul(acc.zz, q.zz), PP);
+  acc.zzz = F::mul(F::mul(acc.zzz, q.zzz), PPP);
+}
+
+// -(x, y) for an affine point with y below 2p
+template <class F> G16_HD void a29_neg(Affine<F>& p) { p.y = F::template neg<2>(p.y); }
+
+// canonical (fp.cuh) <-> lazy conversions
+template <class F, class FC> G16_HD void a29_from_canon(Affine<F>& r, const Affine<FC>& a) {
+  r.x = F::from_canon(a.x);
+  r.y = F::from_canon(a.y);
+}
+template <class F, class FC> G16_HD void x29_to_canon(XYZZ<FC>& r, const XYZZ<F>& p) {
+  if (x29_is_inf(p)) { xyzz_set_inf(r); return; }
+  r.x = F::to_canon(p.x); r.y = F::to_canon(p.y); r.zz = F::to_canon(p.zz); r.zzz = F::to_canon(p.zzz);
+}
+
+}  // namespace g16

@@ -1,0 +1,299 @@
+// BN254 Fq in 9 x 29-bit limbs with lazy reduction -- the MSM kernels' arithmetic.
+//
+// Why (measured, profiles/r01_microbench_int_rates.txt): on gfx950 a v_mad_u64_u32 costs ~5.5
+// cycles per wave-instruction, but so does every carry add (v_add_co/v_addc ~4.5 each,
+// v_lshl_add_u64 ~4.6): the 8 x 32-bit CIOS product of fp.cuh spends more cycles on carries and on
+// building register pairs than on multiplying (129 mad + 129 add64 + 275 mov).  With 29-bit limbs a
+// product column sums 18 terms below 2^58 in ONE 64-bit accumulator without overflow, so the whole
+// Montgomery product is 162 in-place v_mad_u64_u32 plus ~45 cheap ops, and additions are plain
+// limb-wise v_add_u32 followed by one carry ripple.
+//
+// Representation: value = sum l[i] * 2^(29 i); l[0..7] < 2^29 always (every operation ends with a
+// full carry ripple), l[8] holds the rest.  Montgomery radix R' = 2^261.  Values are NOT kept below
+// p: R' leaves 7.4 spare bits, a product of inputs below 16p comes out below 2.51p (in practice
+// ~1.1p), and the few additions/subtractions between products of the curve formulas stay below
+// 16p (bound propagation: tools/f29_bounds.py, asserted at run time in the host test build).
+// Subtraction a - b is a + K*p - b with K*p stored with inflated limbs (no borrows); K is a
+// template parameter chosen per call site from the bound of b.
+//
+// Replaces nothing in the reference by itself: it is the internal number format of the kernels that
+// replace wasmcurves' f1m/curve code (see fp.cuh, ec.cuh); conversion to/from the canonical
+// 8 x 32-bit Montgomery(2^256) image happens when bases are uploaded and when window sums leave the GPU.
+#pragma once
+#include "fp.cuh"
+
+namespace g16 {
+
+struct alignas(4) F29 {
+  uint32_t l[9];
+};
+
+static constexpr uint32_t kM29 = 0x1fffffffu;
+
+struct Fq29C {
+  static constexpr uint32_t P[9] = G16_FQ29_P;
+  static constexpr uint32_t ONE[9] = G16_FQ29_ONE;
+  static constexpr uint32_t TO[9] = G16_FQ29_TO;
+  static constexpr uint32_t FROM[9] = G16_FQ29_FROM;
+  static constexpr uint32_t INV = G16_FQ29_INV;
+};
+template <int K> struct Fq29KP;
+#define G16_DEF_KP(k) \
+  template <> struct Fq29KP<k> { static constexpr uint32_t V[9] = G16_FQ29_KP##k; };
+G16_DEF_KP(1) G16_DEF_KP(2) G16_DEF_KP(3) G16_DEF_KP(4) G16_DEF_KP(5) G16_DEF_KP(6) G16_DEF_KP(7) G16_DEF_KP(8)
+#undef G16_DEF_KP
+
+#if defined(G16_F29_CHECK) && !defined(__HIP_DEVICE_COMPILE__)
+#include <assert.h>
+// host test build: every result must be below 16p (top limb comparison is enough: 16p < 2^258)
+#define G16_F29_ASSERT_BOUND(x) assert((x).l[8] < (16u * Fq29C::P[8] + 16u))
+#define G16_F29_ASSERT_LIMBS(x) do { for (int _i = 0; _i < 8; _i++) assert((x).l[_i] <= kM29); } while (0)
+#else
+#define G16_F29_ASSERT_BOUND(x) ((void)0)
+#define G16_F29_ASSERT_LIMBS(x) ((void)0)
+#endif
+
+G16_HD F29 f29_zero() {
+  F29 r;
+#pragma unroll
+  for (int i = 0; i < 9; i++) r.l[i] = 0;
+  return r;
+}
+G16_HD F29 f29_one() {
+  F29 r;
+#pragma unroll
+  for (int i = 0; i < 9; i++) r.l[i] = Fq29C::ONE[i];
+  return r;
+}
+
+// full carry ripple: limbs 0..7 below 2^29 afterwards (inputs: any limbs whose running sums fit 32 bits)
+G16_HD void f29_carry(F29& a) {
+  uint32_t c = 0;
+#pragma unroll
+  for (int i = 0; i < 8; i++) {
+    const uint32_t v = a.l[i] + c;
+    a.l[i] = v & kM29;
+    c = v >> 29;
+  }
+  a.l[8] += c;
+}
+
+G16_HD F29 f29_add(const F29& a, const F29& b) {
+  F29 r;
+#pragma unroll
+  for (int i = 0; i < 9; i++) r.l[i] = a.l[i] + b.l[i];
+  f29_carry(r);
+  G16_F29_ASSERT_BOUND(r);
+  return r;
+}
+G16_HD F29 f29_dbl(const F29& a) { return f29_add(a, a); }
+
+// a + K*p - b; requires value(b) <= K*p
+template <int K> G16_HD F29 f29_sub(const F29& a, const F29& b) {
+  F29 r;
+#pragma unroll
+  for (int i = 0; i < 9; i++) r.l[i] = a.l[i] + Fq29KP<K>::V[i] - b.l[i];
+  f29_carry(r);
+  G16_F29_ASSERT_BOUND(r);
+  return r;
+}
+template <int K> G16_HD F29 f29_neg(const F29& b) {
+  F29 r;
+#pragma unroll
+  for (int i = 0; i < 9; i++) r.l[i] = Fq29KP<K>::V[i] - b.l[i];
+  f29_carry(r);
+  return r;
+}
+
+// Montgomery product a*b / 2^261 (mod p), product scanning with one 64-bit column accumulator.
+// Inputs: limbs < 2^29 (+ top limb), values < 16p.  Output: limbs exact, value < a*b/2^261 + p.
+G16_HD F29 f29_mul(const F29& a, const F29& b) {
+  G16_F29_ASSERT_LIMBS(a); G16_F29_ASSERT_LIMBS(b);
+  uint64_t acc = 0;
+  uint32_t m[9];
+  F29 r;
+#pragma unroll
+  for (int k = 0; k < 9; k++) {
+#pragma unroll
+    for (int i = 0; i <= k; i++) acc += (uint64_t)a.l[i] * b.l[k - i];
+#pragma unroll
+    for (int i = 0; i < k; i++) acc += (uint64_t)m[i] * Fq29C::P[k - i];
+    m[k] = ((uint32_t)acc * Fq29C::INV) & kM29;
+    acc += (uint64_t)m[k] * Fq29C::P[0];
+    acc >>= 29;
+  }
+#pragma unroll
+  for (int k = 9; k < 17; k++) {
+#pragma unroll
+    for (int i = k - 8; i <= 8; i++) acc += (uint64_t)a.l[i] * b.l[k - i];
+#pragma unroll
+    for (int i = k - 8; i <= 8; i++) acc += (uint64_t)m[i] * Fq29C::P[k - i];
+    r.l[k - 9] = (uint32_t)acc & kM29;
+    acc >>= 29;
+  }
+  r.l[8] = (uint32_t)acc;
+  G16_F29_ASSERT_BOUND(r);
+  return r;
+}
+G16_HD F29 f29_sqr(const F29& a) { return f29_mul(a, a); }
+
+// (a*b + c*d) / 2^261 with ONE reduction (Fq2 products): 27 terms < 2^58 per column still fit.
+G16_HD F29 f29_mul2(const F29& a, const F29& b, const F29& c, const F29& d) {
+  uint64_t acc = 0;
+  uint32_t m[9];
+  F29 r;
+#pragma unroll
+  for (int k = 0; k < 9; k++) {
+#pragma unroll
+    for (int i = 0; i <= k; i++) {
+      acc += (uint64_t)a.l[i] * b.l[k - i];
+      acc += (uint64_t)c.l[i] * d.l[k - i];
+    }
+#pragma unroll
+    for (int i = 0; i < k; i++) acc += (uint64_t)m[i] * Fq29C::P[k - i];
+    m[k] = ((uint32_t)acc * Fq29C::INV) & kM29;
+    acc += (uint64_t)m[k] * Fq29C::P[0];
+    acc >>= 29;
+  }
+#pragma unroll
+  for (int k = 9; k < 17; k++) {
+#pragma unroll
+    for (int i = k - 8; i <= 8; i++) {
+      acc += (uint64_t)a.l[i] * b.l[k - i];
+      acc += (uint64_t)c.l[i] * d.l[k - i];
+    }
+#pragma unroll
+    for (int i = k - 8; i <= 8; i++) acc += (uint64_t)m[i] * Fq29C::P[k - i];
+    r.l[k - 9] = (uint32_t)acc & kM29;
+    acc >>= 29;
+  }
+  r.l[8] = (uint32_t)acc;
+  G16_F29_ASSERT_BOUND(r);
+  return r;
+}
+
+// x == 0 as an integer
+G16_HD bool f29_is_literal_zero(const F29& a) {
+  uint32_t o = 0;
+#pragma unroll
+  for (int i = 0; i < 9; i++) o |= a.l[i];
+  return o == 0;
+}
+// x == 0 (mod p), exact, for any x below 16p: x/2^261 mod p lands in [0, p]
+G16_HD bool f29_is_zero(const F29& a) {
+  F29 one = f29_zero();
+  one.l[0] = 1;
+  const F29 y = f29_mul(a, one);
+  uint32_t z = 0, e = 0;
+#pragma unroll
+  for (int i = 0; i < 9; i++) { z |= y.l[i]; e |= y.l[i] ^ Fq29C::P[i]; }
+  return z == 0 || e == 0;
+}
+// cheap necessary condition for x == 0 (mod p) when x < (KMAX+1)*p: the low limb is exact after
+// the carry ripple, and x = k*p forces it to k*p mod 2^29.
+template <int KMAX> G16_HD bool f29_maybe_zero(const F29& a) {
+  bool hit = false;
+  uint32_t kp = 0;
+#pragma unroll
+  for (int k = 0; k <= KMAX; k++) {
+    hit |= (a.l[0] == (kp & kM29));
+    kp += Fq29C::P[0];
+  }
+  return hit;
+}
+
+// canonical 8 x 32 Montgomery(2^256) image <-> F29 Montgomery(2^261)
+G16_HD F29 f29_from_fq(const Fq& v) {
+  F29 t;
+#pragma unroll
+  for (int i = 0; i < 9; i++) {
+    const int bit = 29 * i, w = bit >> 5, o = bit & 31;
+    uint64_t x = v.v[w];
+    if (w + 1 < 8) x |= (uint64_t)v.v[w + 1] << 32;
+    t.l[i] = (uint32_t)(x >> o) & (i < 8 ? kM29 : 0xffffffffu);
+  }
+  F29 c;
+#pragma unroll
+  for (int i = 0; i < 9; i++) c.l[i] = Fq29C::TO[i];
+  return f29_mul(t, c);
+}
+G16_HD Fq f29_to_fq(const F29& a) {
+  F29 c;
+#pragma unroll
+  for (int i = 0; i < 9; i++) c.l[i] = Fq29C::FROM[i];
+  F29 t = f29_mul(a, c);  // x * 2^256 mod p, in [0, p]
+  // t >= p ? t - p : t   (limbs are exact)
+  uint32_t d[9];
+  int32_t br = 0;
+#pragma unroll
+  for (int i = 0; i < 9; i++) {
+    const int32_t x = (int32_t)t.l[i] - (int32_t)Fq29C::P[i] + br;
+    d[i] = (uint32_t)x & (i < 8 ? kM29 : 0xffffffffu);
+    br = x >> 29;  // arithmetic shift: 0 or -1 (for i < 8)
+    if (i == 8) br = x < 0 ? -1 : 0;
+  }
+  const bool ge = (br == 0);
+  Fq r;
+#pragma unroll
+  for (int i = 0; i < 8; i++) r.v[i] = 0;
+#pragma unroll
+  for (int i = 0; i < 9; i++) {
+    const uint32_t li = ge ? d[i] : t.l[i];
+    const int bit = 29 * i, w = bit >> 5, o = bit & 31;
+    r.v[w] |= li << o;
+    if (o > 3 && w + 1 < 8) r.v[w + 1] |= li >> (32 - o);
+  }
+  return r;
+}
+
+// ------------------------------------------------------------------ Fq2 over F29
+struct alignas(4) F29x2 {
+  F29 a, b;  // a + b*u, u^2 = -1
+};
+
+// Field-ops bundles for ec29.cuh.  sub/neg carry the multiple of p that covers the subtrahend.
+struct Fq29Ops {
+  using T = F29;
+  using Canon = Fq;   // canonical twin (fp.cuh)
+  using CanonOps = FqOps;
+  static G16_HD T zero() { return f29_zero(); }
+  static G16_HD T one() { return f29_one(); }
+  static G16_HD bool is_literal_zero(const T& x) { return f29_is_literal_zero(x); }
+  static G16_HD bool is_zero(const T& x) { return f29_is_zero(x); }
+  template <int KMAX> static G16_HD bool maybe_zero(const T& x) { return f29_maybe_zero<KMAX>(x); }
+  static G16_HD T add(const T& x, const T& y) { return f29_add(x, y); }
+  template <int K> static G16_HD T sub(const T& x, const T& y) { return f29_sub<K>(x, y); }
+  template <int K> static G16_HD T neg(const T& x) { return f29_neg<K>(x); }
+  static G16_HD T mul(const T& x, const T& y) { return f29_mul(x, y); }
+  static G16_HD T sqr(const T& x) { return f29_sqr(x); }
+  static G16_HD T from_canon(const Fq& x) { return f29_from_fq(x); }
+  static G16_HD Fq to_canon(const T& x) { return f29_to_fq(x); }
+};
+
+struct Fq2x29Ops {
+  using T = F29x2;
+  using Canon = Fq2;
+  using CanonOps = Fq2Ops;
+  static G16_HD T zero() { return T{f29_zero(), f29_zero()}; }
+  static G16_HD T one() { return T{f29_one(), f29_zero()}; }
+  static G16_HD bool is_literal_zero(const T& x) { return f29_is_literal_zero(x.a) && f29_is_literal_zero(x.b); }
+  static G16_HD bool is_zero(const T& x) { return f29_is_zero(x.a) && f29_is_zero(x.b); }
+  template <int KMAX> static G16_HD bool maybe_zero(const T& x) {
+    return f29_maybe_zero<KMAX>(x.a) && f29_maybe_zero<KMAX>(x.b);
+  }
+  static G16_HD T add(const T& x, const T& y) { return T{f29_add(x.a, y.a), f29_add(x.b, y.b)}; }
+  template <int K> static G16_HD T sub(const T& x, const T& y) {
+    return T{f29_sub<K>(x.a, y.a), f29_sub<K>(x.b, y.b)};
+  }
+  template <int K> static G16_HD T neg(const T& x) { return T{f29_neg<K>(x.a), f29_neg<K>(x.b)}; }
+  // (a0 b0 - a1 b1) + (a0 b1 + a1 b0) u, two fused reductions; components of x below 8p
+  static G16_HD T mul(const T& x, const T& y) {
+    const F29 nb = f29_neg<8>(x.b);
+    return T{f29_mul2(x.a, y.a, nb, y.b), f29_mul2(x.a, y.b, x.b, y.a)};
+  }
+  static G16_HD T sqr(const T& x) { return mul(x, x); }
+  static G16_HD T from_canon(const Fq2& x) { return T{f29_from_fq(x.a), f29_from_fq(x.b)}; }
+  static G16_HD Fq2 to_canon(const T& x) { return Fq2{f29_to_fq(x.a), f29_to_fq(x.b)}; }
+};
+
+}  // namespace g16

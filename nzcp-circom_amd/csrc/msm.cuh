@@ -23,6 +23,7 @@
 // v_mad_u64_u32: the kernel is integer-VALU bound by two orders of magnitude, HBM sees one
 // random 64 B read per add.
 #pragma once
+#include "ec29.cuh"
 #include "internal.h"
 
 namespace g16 {
@@ -46,6 +47,7 @@ struct MsmWorkspace {
   uint32_t max_heavy = 0;
   void* d_seg = nullptr;
   void* d_red = nullptr;
+  void* d_canon = nullptr;        // (W+1) canonical XYZZ window sums
   uint8_t* h_pinned = nullptr;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;  // around the bucket-accumulate kernel
   float last_accum_ms = 0.f;
@@ -283,23 +285,23 @@ __global__ __launch_bounds__(64) void msm_accumulate_kernel(const Affine<F>* __r
   uint32_t len = cntb - k * task_len;
   if (len > task_len) len = task_len;
   XYZZ<F> acc;
-  xyzz_set_inf(acc);
+  x29_set_inf(acc);
   for (uint32_t e = start; e < start + len; e++) {
     const uint32_t idx = sorted[e];
     Affine<F> p = bases[idx & 0x7fffffffu];
-    if (idx >> 31) p.y = F::neg(p.y);
-    xyzz_madd(acc, p);
+    if (idx >> 31) a29_neg(p);
+    x29_madd(acc, p);
   }
   partial[t] = acc;
 }
 
 template <class F>
 __device__ __forceinline__ void msm_mul_small(XYZZ<F>& r, const XYZZ<F>& p, uint32_t k) {
-  xyzz_set_inf(r);
+  x29_set_inf(r);
   if (k == 0) return;
   for (int i = 31 - __clz(k); i >= 0; i--) {
-    xyzz_dbl(r);
-    if ((k >> i) & 1) xyzz_add(r, p);
+    x29_dbl(r);
+    if ((k >> i) & 1) x29_add(r, p);
   }
 }
 
@@ -325,7 +327,7 @@ __global__ __launch_bounds__(64) void msm_combine_light_kernel(const XYZZ<F>* __
   if (b >= nb) return;
   const uint32_t t0 = toff[b], t1 = toff[b + 1];
   XYZZ<F> acc;
-  xyzz_set_inf(acc);
+  x29_set_inf(acc);
   if (t1 - t0 > kLightTasks) {
     const uint32_t k = atomicAdd(&heavy[0], 1u);
     if (k < max_heavy) heavy[1 + k] = b;   // cannot overflow: max_heavy >= max_tasks / kLightTasks
@@ -333,7 +335,7 @@ __global__ __launch_bounds__(64) void msm_combine_light_kernel(const XYZZ<F>* __
   }
   for (uint32_t t = t0; t < t1; t++) {
     const XYZZ<F> s = partial[t];
-    xyzz_add(acc, s);
+    x29_add(acc, s);
   }
   bsum[b] = acc;
 }
@@ -351,14 +353,14 @@ __global__ __launch_bounds__(64) void msm_combine_heavy_kernel(const XYZZ<F>* __
     const uint32_t b = heavy[1 + h];
     const uint32_t t0 = toff[b], t1 = toff[b + 1];
     XYZZ<F> acc;
-    xyzz_set_inf(acc);
+    x29_set_inf(acc);
     for (uint32_t t = t0 + lane; t < t1; t += 64) {
       const XYZZ<F> s = partial[t];
-      xyzz_add(acc, s);
+      x29_add(acc, s);
     }
     for (int d = 32; d >= 1; d >>= 1) {
       const XYZZ<F> q = xyzz_shfl_down(acc, d);
-      xyzz_add(acc, q);
+      x29_add(acc, q);
     }
     if (lane == 0) bsum[b] = acc;
   }
@@ -376,19 +378,19 @@ __global__ __launch_bounds__(64) void msm_bucket_reduce_kernel(const XYZZ<F>* __
   const uint32_t lo = g * kSegLen;
   const uint32_t hi = (lo + kSegLen < B) ? lo + kSegLen : B;
   XYZZ<F> run, acc;
-  xyzz_set_inf(run);
-  xyzz_set_inf(acc);
+  x29_set_inf(run);
+  x29_set_inf(acc);
   for (uint32_t bi = hi; bi-- > lo;) {
     const XYZZ<F> s = bsum[(size_t)j * B + bi];
-    xyzz_add(run, s);
-    if (!plain) xyzz_add(acc, run);
+    x29_add(run, s);
+    if (!plain) x29_add(acc, run);
   }
   if (plain) {
     acc = run;
   } else if (lo != 0) {
     XYZZ<F> m;
     msm_mul_small(m, run, lo);
-    xyzz_add(acc, m);
+    x29_add(acc, m);
   }
   seg[tid] = acc;
 }
@@ -401,12 +403,33 @@ __global__ __launch_bounds__(64) void msm_wave_reduce_kernel(const XYZZ<F>* __re
   const uint32_t i = blk * 64 + lane;
   XYZZ<F> p;
   if (i < nin) p = in[(size_t)j * nin + i];
-  else xyzz_set_inf(p);
+  else x29_set_inf(p);
   for (int d = 32; d >= 1; d >>= 1) {
     const XYZZ<F> q = xyzz_shfl_down(p, d);
-    xyzz_add(p, q);
+    x29_add(p, q);
   }
   if (lane == 0) out[(size_t)j * nout + blk] = p;
+}
+
+// bases: canonical affine image (zkey bytes) -> lazy 9x29 representation, once at create
+template <class F>
+__global__ __launch_bounds__(256) void msm_convert_bases_kernel(const Affine<typename F::CanonOps>* __restrict__ in,
+                                                                Affine<F>* __restrict__ out, uint32_t n) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  Affine<F> r;
+  a29_from_canon<F, typename F::CanonOps>(r, in[i]);
+  out[i] = r;
+}
+// window sums: lazy -> canonical XYZZ (what the host folds)
+template <class F>
+__global__ __launch_bounds__(64) void msm_to_canon_kernel(const XYZZ<F>* __restrict__ in,
+                                                          XYZZ<typename F::CanonOps>* __restrict__ out, uint32_t n) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  XYZZ<typename F::CanonOps> r;
+  x29_to_canon<F, typename F::CanonOps>(r, in[i]);
+  out[i] = r;
 }
 
 // ------------------------------------------------------------------ host side (per curve)
@@ -425,7 +448,8 @@ int msm_launch_t(const MsmInstance& m, MsmWorkspace* ws, const Fr* d_scalars, hi
   const uint32_t W = (uint32_t)m.W, B = m.nbuckets, WT = W + 1, nb = WT * B;  // + the ones window
   ws->last_accum_ms = 0.f;
   ws->launched_n = m.n;
-  ws->out_bytes = (size_t)WT * sizeof(PT);
+  using CPT = XYZZ<typename F::CanonOps>;
+  ws->out_bytes = (size_t)WT * sizeof(CPT);
   if (m.n == 0) return G16_OK;
   const uint32_t nseg = (B + kSegLen - 1) / kSegLen;
   U256 K;
@@ -479,7 +503,9 @@ int msm_launch_t(const MsmInstance& m, MsmWorkspace* ws, const Fr* d_scalars, hi
     cnt = nout;
   }
   G16_HIP(hipGetLastError());
-  G16_HIP(hipMemcpyAsync(ws->h_pinned, cur, (size_t)WT * sizeof(PT), hipMemcpyDeviceToHost, st));
+  msm_to_canon_kernel<F><<<(WT + 63) / 64, 64, 0, st>>>(cur, (CPT*)ws->d_canon, WT);
+  G16_HIP(hipGetLastError());
+  G16_HIP(hipMemcpyAsync(ws->h_pinned, ws->d_canon, (size_t)WT * sizeof(CPT), hipMemcpyDeviceToHost, st));
   return G16_OK;
 }
 

@@ -7,6 +7,14 @@ namespace g16 {
 
 size_t msm_point_bytes(int curve) { return curve == 2 ? sizeof(G2XYZZ) : sizeof(G1XYZZ); }
 
+int msm_convert_bases_g2(const void* in, void* out, uint32_t n);
+static int msm_convert_bases_g1(const void* in, void* out, uint32_t n) {
+  msm_convert_bases_kernel<Fq29Ops><<<(n + 255) / 256, 256>>>((const G1Affine*)in, (G1Affine29*)out, n);
+  G16_HIP(hipGetLastError());
+  G16_HIP(hipDeviceSynchronize());
+  return G16_OK;
+}
+
 static int choose_c(uint32_t n) {
   // minimise W * (n + 2.5 * 2^(c-1)) over c in [4, 16], W = ceil(256 / c)
   int best = 4;
@@ -56,10 +64,17 @@ int msm_instance_create(MsmInstance& m, int curve, const uint8_t* bases_host, ui
     m.task_len = (uint32_t)(t < 16 ? 16 : (t > 256 ? 256 : t));
   }
   if (m.n) {
-    G16_HIP(hipMalloc(&m.d_bases, packed.size()));
+    // upload the canonical image, convert once on the device to the kernels' 9x29 representation
+    void* tmp = nullptr;
+    const size_t lazy_bytes = (size_t)m.n * (curve == 2 ? sizeof(G2Affine29) : sizeof(G1Affine29));
+    G16_HIP(hipMalloc(&tmp, packed.size()));
+    G16_HIP(hipMalloc(&m.d_bases, lazy_bytes));
     G16_HIP(hipMalloc(&m.d_src, (size_t)m.n * 4));
-    G16_HIP(hipMemcpy(m.d_bases, packed.data(), packed.size(), hipMemcpyHostToDevice));
+    G16_HIP(hipMemcpy(tmp, packed.data(), packed.size(), hipMemcpyHostToDevice));
     G16_HIP(hipMemcpy(m.d_src, src.data(), (size_t)m.n * 4, hipMemcpyHostToDevice));
+    int rc = curve == 2 ? msm_convert_bases_g2(tmp, m.d_bases, m.n) : msm_convert_bases_g1(tmp, m.d_bases, m.n);
+    (void)hipFree(tmp);
+    if (rc) return rc;
   }
   return G16_OK;
 }
@@ -81,7 +96,8 @@ int msm_workspace_create(MsmWorkspace** out, const MsmInstance* insts, int ninst
     const uint64_t entries = (uint64_t)m.n * m.W;
     const uint64_t tasks = nb + entries / m.task_len + 64;
     const uint64_t nseg = (m.nbuckets + kSegLen - 1) / kSegLen;
-    const size_t pb = msm_point_bytes(m.curve);
+    const size_t pb = m.curve == 2 ? sizeof(G2XYZZ29) : sizeof(G1XYZZ29);   // device-side (lazy) points
+    const size_t cpb = msm_point_bytes(m.curve);                             // canonical, host-visible
     if (entries > ws->max_entries) ws->max_entries = (uint32_t)entries;
     if (nb > ws->max_buckets) ws->max_buckets = (uint32_t)nb;
     if (tasks > ws->max_tasks) ws->max_tasks = (uint32_t)tasks;
@@ -90,7 +106,7 @@ int msm_workspace_create(MsmWorkspace** out, const MsmInstance* insts, int ninst
     if ((m.W + 1) * nseg * pb > seg_bytes) seg_bytes = (m.W + 1) * nseg * pb;
     const size_t rb = 2 * (size_t)(m.W + 1) * ((nseg + 63) / 64) * pb;
     if (rb > red_bytes) red_bytes = rb;
-    if ((size_t)(m.W + 1) * pb > pin_bytes) pin_bytes = (size_t)(m.W + 1) * pb;
+    if ((size_t)(m.W + 1) * cpb > pin_bytes) pin_bytes = (size_t)(m.W + 1) * cpb;
   }
   *out = ws;
   // sort geometry: ~4 workgroups of 1024 threads per CU when the LDS histogram allows it
@@ -126,6 +142,7 @@ int msm_workspace_create(MsmWorkspace** out, const MsmInstance* insts, int ninst
   G16_HIP(hipMalloc(&ws->d_seg, seg_bytes + 256));
   G16_HIP(hipMalloc(&ws->d_red, red_bytes + 256));
   G16_HIP(hipHostMalloc((void**)&ws->h_pinned, pin_bytes + 256));
+  G16_HIP(hipMalloc(&ws->d_canon, pin_bytes + 256));
   G16_HIP(hipEventCreate(&ws->ev0));
   G16_HIP(hipEventCreate(&ws->ev1));
   return G16_OK;
@@ -134,7 +151,7 @@ int msm_workspace_create(MsmWorkspace** out, const MsmInstance* insts, int ninst
 void msm_workspace_destroy(MsmWorkspace* ws) {
   if (!ws) return;
   void* ptrs[] = {ws->d_cnt, ws->d_off, ws->d_cursor, ws->d_toff, ws->d_sorted, ws->d_task_bucket, ws->d_tile_a, ws->d_tile_b,
-                  ws->d_partial, ws->d_seg, ws->d_red, ws->d_bsum, ws->d_heavy, ws->d_dig, ws->d_hist};
+                  ws->d_partial, ws->d_seg, ws->d_red, ws->d_bsum, ws->d_heavy, ws->d_dig, ws->d_hist, ws->d_canon};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   if (ws->h_pinned) (void)hipHostFree(ws->h_pinned);
@@ -149,7 +166,7 @@ float msm_last_accum_ms(const MsmWorkspace* ws) { return ws->last_accum_ms; }
 
 int msm_launch(const MsmInstance& m, MsmWorkspace* ws, const Fr* d_scalars, hipStream_t st) {
   if (m.curve == 2) return msm_launch_g2(m, ws, d_scalars, st);
-  return msm_launch_t<FqOps>(m, ws, d_scalars, st);
+  return msm_launch_t<Fq29Ops>(m, ws, d_scalars, st);
 }
 
 int msm_collect(MsmWorkspace* ws, uint8_t* out_windows, hipStream_t st) {

@@ -268,7 +268,10 @@ static int create_impl(const uint8_t* zkey, size_t len, const g16_opts* opts, g1
   P->shard_rank = opts ? opts->shard_rank : 0;
   if (P->shard_rank < 0 || P->shard_rank >= P->shard_count) { set_error("shard_rank out of range"); return G16_E_ARG; }
   if ((rc = check_device(P->device))) return rc;
-  G16_HIP(hipStreamCreate(&P->st));
+  // main stream (QAP -> NTT -> H-MSM, the critical path) at high priority, witness MSM streams low
+  int prio_lo = 0, prio_hi = 0;
+  G16_HIP(hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
+  G16_HIP(hipStreamCreateWithPriority(&P->st, hipStreamNonBlocking, prio_hi));
   for (auto& e : P->ev) G16_HIP(hipEventCreate(&e));
   if ((rc = build_csr(P, s4))) return rc;
   if ((rc = ntt_tables_create(P->ntt, P->L, P->st))) return rc;
@@ -293,7 +296,7 @@ static int create_impl(const uint8_t* zkey, size_t len, const g16_opts* opts, g1
   }
   for (int i = 0; i < 5; i++) {
     if ((rc = msm_workspace_create(&P->ws[i], &P->msm[i], 1))) return rc;
-    if (i < 4) G16_HIP(hipStreamCreateWithFlags(&P->mst[i], hipStreamNonBlocking));
+    if (i < 4) G16_HIP(hipStreamCreateWithPriority(&P->mst[i], hipStreamNonBlocking, prio_lo));
     else P->mst[4] = P->st;
     G16_HIP(hipEventCreate(&P->mev[i][0]));
     G16_HIP(hipEventCreate(&P->mev[i][1]));
@@ -375,7 +378,9 @@ static int device_impl(g16_prover* P, uint32_t slot, Partial& out) {
   const Fr* d_w = P->slot_dev[slot];
   int rc;
   G16_HIP(hipEventRecord(P->ev[2], P->st));
-  for (int i = 0; i < 4; i++) {
+  static const int order[4] = {2, 3, 0, 1};   // longest chains first: B2 (G2), C, A, B1
+  for (int oi = 0; oi < 4; oi++) {
+    const int i = order[oi];
     G16_HIP(hipStreamWaitEvent(P->mst[i], P->ev[2], 0));
     G16_HIP(hipEventRecord(P->mev[i][0], P->mst[i]));
     if ((rc = msm_launch(P->msm[i], P->ws[i], d_w, P->mst[i]))) return rc;
