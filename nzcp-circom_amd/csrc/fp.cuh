@@ -135,6 +135,36 @@ template <class PM> G16_HD Fp<PM> fp_dbl(const Fp<PM>& a) { return fp_add(a, a);
 // Montgomery product a*b*R^-1 mod p, CIOS.  p < 2^254 so the running value stays < 2p and the
 // ninth word never needs a second carry word.
 template <class PM> G16_HD Fp<PM> fp_mul(const Fp<PM>& a, const Fp<PM>& b) {
+#if !defined(__HIP_DEVICE_COMPILE__) && defined(__SIZEOF_INT128__) && !defined(G16_HOST_MUL32)
+  // Host build (proof tail, window folding, setup tool): same CIOS on 4 x 64-bit limbs, ~3.5x
+  // faster than the 32-bit form on x86.  The 32-bit form below is what the device runs.
+  typedef unsigned __int128 u128;
+  uint64_t A[4], B[4], P[4], t[5] = {0, 0, 0, 0, 0};
+  for (int i = 0; i < 4; i++) {
+    A[i] = a.v[2 * i] | ((uint64_t)a.v[2 * i + 1] << 32);
+    B[i] = b.v[2 * i] | ((uint64_t)b.v[2 * i + 1] << 32);
+    P[i] = PM::P[2 * i] | ((uint64_t)PM::P[2 * i + 1] << 32);
+  }
+  // -p^-1 mod 2^64 from the 32-bit constant by one Newton step: x' = x (2 + p x)  (x = -p^-1)
+  const uint64_t inv32 = PM::INV;
+  const uint64_t inv64 = inv32 * (2 + P[0] * inv32);
+  for (int i = 0; i < 4; i++) {
+    u128 c = 0;
+    for (int j = 0; j < 4; j++) { c += (u128)A[j] * B[i] + t[j]; t[j] = (uint64_t)c; c >>= 64; }
+    const uint64_t t4 = t[4] + (uint64_t)c;
+    const uint64_t m = t[0] * inv64;
+    c = (u128)m * P[0] + t[0];
+    c >>= 64;
+    for (int j = 1; j < 4; j++) { c += (u128)m * P[j] + t[j]; t[j - 1] = (uint64_t)c; c >>= 64; }
+    c += t4;
+    t[3] = (uint64_t)c;
+    t[4] = (uint64_t)(c >> 64);
+  }
+  Fp<PM> r;
+  for (int i = 0; i < 4; i++) { r.v[2 * i] = (uint32_t)t[i]; r.v[2 * i + 1] = (uint32_t)(t[i] >> 32); }
+  fp_reduce_once(r);
+  return r;
+#else
   uint32_t t[9];
 #pragma unroll
   for (int i = 0; i < 9; i++) t[i] = 0;
@@ -167,6 +197,7 @@ template <class PM> G16_HD Fp<PM> fp_mul(const Fp<PM>& a, const Fp<PM>& b) {
   for (int i = 0; i < 8; i++) r.v[i] = t[i];
   fp_reduce_once(r);
   return r;
+#endif
 }
 
 template <class PM> G16_HD Fp<PM> fp_sqr(const Fp<PM>& a) { return fp_mul(a, a); }
