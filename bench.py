@@ -162,11 +162,20 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback)"
-    torch.cuda.set_device(local)
+    # Rehearsal knobs (the driver never sets them): G16_BENCH_DEVICE pins every rank to one GPU and
+    # G16_BENCH_BACKEND=gloo exchanges the partial sums over gloo, so the N > 1 code path can be
+    # exercised end to end on a 1-GPU box.  Default: one rank per GPU, RCCL ("nccl") over xGMI.
+    dev = int(os.environ.get("G16_BENCH_DEVICE", local))
+    backend = os.environ.get("G16_BENCH_BACKEND", "nccl")
+    torch.cuda.set_device(dev)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", dev))
+        else:
+            dist.init_process_group(backend)
+    xdev = "cuda" if backend == "nccl" else "cpu"
 
     def log(msg):
         if rank == 0:
@@ -182,7 +191,7 @@ def main():
         f"zkey {len(zkey) / 1e6:.0f} MB")
     sharded = world > 1 and args.mode == "shard"
     t0 = time.time()
-    prover = amd.Prover(zkey, device=local, shard_rank=rank if sharded else 0,
+    prover = amd.Prover(zkey, device=dev, shard_rank=rank if sharded else 0,
                         shard_count=world if sharded else 1, window_bits=args.window_bits,
                         task_len=args.task_len)
     if world > 1 or args.no_cpu:
@@ -196,8 +205,8 @@ def main():
     r, s = fixed_rs(SEED)
     pr = amd.Proof()
     pub = ctypes.create_string_buffer(max(1, args.n_public * 32))
-    gather_in = torch.zeros(amd.PARTIAL_BYTES, dtype=torch.uint8, device="cuda")
-    gather_out = torch.zeros(amd.PARTIAL_BYTES * world, dtype=torch.uint8, device="cuda")
+    gather_in = torch.zeros(amd.PARTIAL_BYTES, dtype=torch.uint8, device=xdev)
+    gather_out = torch.zeros(amd.PARTIAL_BYTES * world, dtype=torch.uint8, device=xdev)
     lib = amd.load()
     pbuf = ctypes.create_string_buffer(amd.PARTIAL_BYTES)
 
@@ -235,7 +244,7 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device=xdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     K = args.steps

@@ -35,7 +35,8 @@ struct MsmWorkspace {
   uint32_t* d_cursor = nullptr;
   uint32_t* d_toff = nullptr;
   uint32_t* d_sorted = nullptr;
-  uint32_t* d_task_bucket = nullptr;
+  uint2* d_task_desc = nullptr;
+  uint32_t* d_queue = nullptr;    // work-queue head of the accumulate kernel
   uint32_t* d_tile_a = nullptr;
   uint32_t* d_tile_b = nullptr;
   uint32_t* d_dig = nullptr;      // [(W+1)][n] digit codes (window-major)
@@ -262,37 +263,97 @@ static __global__ __launch_bounds__(256) void msm_scan_apply_kernel(const uint32
   }
 }
 
-static __global__ __launch_bounds__(256) void msm_task_fill_kernel(const uint32_t* __restrict__ toff, uint32_t nb,
-                                                            uint32_t* __restrict__ task_bucket) {
+// task descriptor = (first sorted entry, entry count); tasks of one bucket are consecutive
+static __global__ __launch_bounds__(256) void msm_task_fill_kernel(const uint32_t* __restrict__ off,
+                                                            const uint32_t* __restrict__ toff, uint32_t nb,
+                                                            uint32_t task_len, uint2* __restrict__ task_desc) {
   const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= nb) return;
-  for (uint32_t t = toff[b], e = toff[b + 1]; t < e; t++) task_bucket[t] = b;
+  uint32_t start = off[b], left = off[b + 1] - start;
+  for (uint32_t t = toff[b], e = toff[b + 1]; t < e; t++) {
+    const uint32_t len = left < task_len ? left : task_len;
+    task_desc[t] = make_uint2(start, len);
+    start += len;
+    left -= len;
+  }
 }
 
+// Bucket accumulation: persistent wavefronts over a work queue.  A wavefront pulls chunks of
+// kTaskChunk consecutive tasks from a global counter; a lane that finishes its task takes the
+// chunk's next one (ballot + prefix popcount), so lanes stay busy instead of idling behind the
+// longest bucket, and there is no grid-quantisation tail.  The descriptor of a newly assigned task
+// is loaded when the lane runs dry and consumed one iteration later: the wave never stalls on it
+// while the other lanes are adding.  Exit: the queue counter passes `total` (every wave sees it).
+static constexpr uint32_t kTaskChunk = 64;
+
 template <class F>
-__global__ __launch_bounds__(64) void msm_accumulate_kernel(const Affine<F>* __restrict__ bases,
+__global__ __launch_bounds__(64, F::kAccumWavesPerSimd) void msm_accumulate_kernel(const Affine<F>* __restrict__ bases,
                                                             const uint32_t* __restrict__ sorted,
-                                                            const uint32_t* __restrict__ off,
                                                             const uint32_t* __restrict__ toff, uint32_t nb,
-                                                            const uint32_t* __restrict__ task_bucket,
-                                                            uint32_t task_len, XYZZ<F>* __restrict__ partial) {
-  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= toff[nb]) return;
-  const uint32_t b = task_bucket[t];
-  const uint32_t k = t - toff[b];
-  const uint32_t cntb = off[b + 1] - off[b];
-  const uint32_t start = off[b] + k * task_len;
-  uint32_t len = cntb - k * task_len;
-  if (len > task_len) len = task_len;
+                                                            const uint2* __restrict__ task_desc,
+                                                            uint32_t* __restrict__ queue,
+                                                            XYZZ<F>* __restrict__ partial) {
+  const uint32_t total = toff[nb];
+  const uint32_t lane = threadIdx.x;
+  const unsigned long long lt_mask = (1ull << lane) - 1;
+  constexpr uint32_t kNone = 0xffffffffu;
+  uint32_t next = 0, chunk_end = 0;     // wave-uniform: the chunk being handed out
+  bool exhausted = false;               // wave-uniform: the queue has no more chunks
+  uint32_t my_task = kNone, pending = kNone, cur = 0, end = 0;
+  uint2 desc = make_uint2(0, 0);
   XYZZ<F> acc;
   x29_set_inf(acc);
-  for (uint32_t e = start; e < start + len; e++) {
-    const uint32_t idx = sorted[e];
-    Affine<F> p = bases[idx & 0x7fffffffu];
-    if (idx >> 31) a29_neg(p);
-    x29_madd(acc, p);
+  for (;;) {
+    // 1. lanes whose descriptor arrived start their task
+    if (pending != kNone) {
+      my_task = pending;
+      pending = kNone;
+      cur = desc.x;
+      end = desc.x + desc.y;
+      x29_set_inf(acc);
+    }
+    // 2. lanes that ran dry flush and ask for the next task
+    const bool finished = (my_task != kNone && cur == end);
+    const bool dry = finished || (my_task == kNone && pending == kNone && !exhausted);
+    const unsigned long long m = __ballot(dry);
+    if (m) {
+      if (finished) {
+        partial[my_task] = acc;
+        my_task = kNone;
+      }
+      if (next == chunk_end && !exhausted) {   // wave-uniform: pull the next chunk
+        uint32_t base = 0;
+        if (lane == 0) base = atomicAdd(queue, kTaskChunk);
+        base = __shfl(base, 0, 64);
+        if (base >= total) {
+          exhausted = true;
+        } else {
+          next = base;
+          chunk_end = base + kTaskChunk < total ? base + kTaskChunk : total;
+        }
+      }
+      if (dry && !exhausted) {
+        const uint32_t cand = next + (uint32_t)__popcll(m & lt_mask);
+        if (cand < chunk_end) {
+          pending = cand;
+          desc = task_desc[cand];
+        }
+      }
+      if (!exhausted) {
+        next += (uint32_t)__popcll(m);
+        if (next > chunk_end) next = chunk_end;
+      }
+    }
+    // 3. done when no lane holds or awaits a task and the queue is empty
+    if (exhausted && __ballot(my_task != kNone || pending != kNone) == 0) break;
+    // 4. one mixed addition per busy lane
+    if (my_task != kNone) {
+      const uint32_t idx = sorted[cur++];
+      Affine<F> p = bases[idx & 0x7fffffffu];
+      if (idx >> 31) a29_neg(p);
+      x29_madd(acc, p);
+    }
   }
-  partial[t] = acc;
 }
 
 template <class F>
@@ -475,13 +536,18 @@ int msm_launch_t(const MsmInstance& m, MsmWorkspace* ws, const Fr* d_scalars, hi
                                                 ws->d_cursor, ws->d_toff);
   msm_hist_start_kernel<<<(nb + 255) / 256, 256, 0, st>>>(ws->d_hist, nb, B, chunks, ws->d_off);
   msm_sort_kernel<1><<<WT * chunks, 1024, lds_bytes, st>>>(ws->d_dig, m.n, B, chunks, per, ws->d_hist, ws->d_sorted);
-  msm_task_fill_kernel<<<(nb + 255) / 256, 256, 0, st>>>(ws->d_toff, nb, ws->d_task_bucket);
+  msm_task_fill_kernel<<<(nb + 255) / 256, 256, 0, st>>>(ws->d_off, ws->d_toff, nb, m.task_len, ws->d_task_desc);
   // upper bound on tasks: every non-empty bucket has <= 1 short task + entries/task_len full ones
   const uint64_t max_tasks = (uint64_t)nb + ((uint64_t)m.n * W) / m.task_len;  // ones: <= n entries, covered
+  // persistent grid: as many wavefronts as the chip holds for this kernel (4/SIMD G1, 2/SIMD G2), fewer
+  // when there is little work
+  uint64_t waves = (uint64_t)256 * 4 * (sizeof(typename F::T) > sizeof(F29) ? 2 : 4);
+  if (waves > (max_tasks + kTaskChunk - 1) / kTaskChunk) waves = (max_tasks + kTaskChunk - 1) / kTaskChunk;
+  if (waves == 0) waves = 1;
+  G16_HIP(hipMemsetAsync(ws->d_queue, 0, 4, st));
   G16_HIP(hipEventRecord(ws->ev0, st));
-  msm_accumulate_kernel<F><<<(unsigned)((max_tasks + 63) / 64), 64, 0, st>>>(
-      (const Affine<F>*)m.d_bases, ws->d_sorted, ws->d_off, ws->d_toff, nb, ws->d_task_bucket, m.task_len,
-      (PT*)ws->d_partial);
+  msm_accumulate_kernel<F><<<(unsigned)waves, 64, 0, st>>>((const Affine<F>*)m.d_bases, ws->d_sorted, ws->d_toff, nb,
+                                                            ws->d_task_desc, ws->d_queue, (PT*)ws->d_partial);
   G16_HIP(hipEventRecord(ws->ev1, st));
   G16_HIP(hipMemsetAsync(ws->d_heavy, 0, 4, st));
   msm_combine_light_kernel<F><<<(nb + 63) / 64, 64, 0, st>>>((const PT*)ws->d_partial, ws->d_toff, nb,

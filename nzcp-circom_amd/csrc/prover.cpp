@@ -296,7 +296,8 @@ static int create_impl(const uint8_t* zkey, size_t len, const g16_opts* opts, g1
   }
   for (int i = 0; i < 5; i++) {
     if ((rc = msm_workspace_create(&P->ws[i], &P->msm[i], 1))) return rc;
-    if (i < 4) G16_HIP(hipStreamCreateWithPriority(&P->mst[i], hipStreamNonBlocking, prio_lo));
+    // the G2 chain (B2) is the longest after the H chain: high priority as well
+    if (i < 4) G16_HIP(hipStreamCreateWithPriority(&P->mst[i], hipStreamNonBlocking, i == 2 ? prio_hi : prio_lo));
     else P->mst[4] = P->st;
     G16_HIP(hipEventCreate(&P->mev[i][0]));
     G16_HIP(hipEventCreate(&P->mev[i][1]));
