@@ -12,10 +12,10 @@
 
 namespace g16 {
 
-template <class F> struct Affine {
+template <class F> struct alignas(16) Affine {
   typename F::T x, y;
 };
-template <class F> struct XYZZ {
+template <class F> struct alignas(16) XYZZ {
   typename F::T x, y, zz, zzz;
 };
 using G1Affine = Affine<FqOps>;

@@ -24,8 +24,9 @@
 
 namespace g16 {
 
-struct alignas(4) F29 {
+struct alignas(8) F29 {   // 9 limbs + 1 pad word: 40 bytes, so points are 16-byte multiples (dwordx4 gathers)
   uint32_t l[9];
+  uint32_t pad_;
 };
 
 static constexpr uint32_t kM29 = 0x1fffffffu;
@@ -259,7 +260,7 @@ G16_HD Fq f29_to_fq(const F29& a) {
 }
 
 // ------------------------------------------------------------------ Fq2 over F29
-struct alignas(4) F29x2 {
+struct alignas(8) F29x2 {
   F29 a, b;  // a + b*u, u^2 = -1
 };
 

@@ -61,7 +61,7 @@ int msm_instance_create(MsmInstance& m, int curve, const uint8_t* bases_host, ui
   } else {
     const uint64_t entries = (uint64_t)n_eff * m.W;
     uint64_t t = entries / 262144;
-    m.task_len = (uint32_t)(t < 16 ? 16 : (t > 256 ? 256 : t));
+    m.task_len = (uint32_t)(t < 16 ? 16 : (t > 32 ? 32 : t));   // short tasks: small drain tail (sweep r01)
   }
   if (m.n) {
     // upload the canonical image, convert once on the device to the kernels' 9x29 representation

@@ -146,7 +146,7 @@ struct g16_prover {
     ntt_tables_destroy(ntt);
     for (auto& m : msm) msm_instance_destroy(m);
     for (auto& w : ws) msm_workspace_destroy(w);
-    for (int i = 0; i < 4; i++) if (mst[i]) (void)hipStreamDestroy(mst[i]);
+    for (int i = 0; i < 4; i++) if (mst[i] && mst[i] != st) (void)hipStreamDestroy(mst[i]);
     for (auto& e : mev) { if (e[0]) (void)hipEventDestroy(e[0]); if (e[1]) (void)hipEventDestroy(e[1]); }
     for (auto& e : ev) if (e) (void)hipEventDestroy(e);
     if (st) (void)hipStreamDestroy(st);
@@ -297,7 +297,10 @@ static int create_impl(const uint8_t* zkey, size_t len, const g16_opts* opts, g1
   for (int i = 0; i < 5; i++) {
     if ((rc = msm_workspace_create(&P->ws[i], &P->msm[i], 1))) return rc;
     // the G2 chain (B2) is the longest after the H chain: high priority as well
-    if (i < 4) G16_HIP(hipStreamCreateWithPriority(&P->mst[i], hipStreamNonBlocking, i == 2 ? prio_hi : prio_lo));
+    // G16_SERIAL_MSM=1 (profiling aid): every MSM on the main stream, so kernel times are standalone
+    const bool serial = getenv("G16_SERIAL_MSM") && atoi(getenv("G16_SERIAL_MSM"));
+    if (i < 4 && serial) P->mst[i] = P->st;
+    else if (i < 4) G16_HIP(hipStreamCreateWithPriority(&P->mst[i], hipStreamNonBlocking, i == 2 ? prio_hi : prio_lo));
     else P->mst[4] = P->st;
     G16_HIP(hipEventCreate(&P->mev[i][0]));
     G16_HIP(hipEventCreate(&P->mev[i][1]));
