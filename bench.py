@@ -142,6 +142,53 @@ def cpu_leg(amd, args, full_proof, full_pub, full_vkey, full_zkey, full_wtns, fu
             "sample_seconds": round(t_cpu, 3)}
 
 
+def batch_leg(amd, args, zkey, wtns, prover0, r, s, log):
+    """Throughput mode (BASELINE config 3, "batch of independent witnesses, 1-GPU throughput mode"):
+    `batch_streams` resident prover handles (own streams/workspaces, same key) fed from host threads,
+    each proving its share of `batch_proofs` independent satisfying witnesses.  Reported next to the
+    single-proof `value`, never instead of it."""
+    import threading
+    nthreads = args.batch_streams
+    provers = [prover0] + [amd.Prover(zkey, device=0, window_bits=args.window_bits, task_len=args.task_len)
+                           for _ in range(nthreads - 1)]
+    nslots = 4
+    wts = [wtns] + [amd.synth_witness(args.n_vars, args.n_public, args.n_constraints, SEED, SEED + 100 + i)
+                    for i in range(1, nslots)]
+    for pv in provers:
+        for k, w in enumerate(wts):
+            pv.stage(k, w)
+    total = args.batch_proofs
+    outs = [[] for _ in range(nthreads)]
+
+    def work(t):
+        pr, pub = amd.Proof(), ctypes.create_string_buffer(max(1, args.n_public * 32))
+        for i in range(t, total, nthreads):
+            rc = provers[t].prove_staged_raw(i % nslots, r, s, pr, pub)
+            assert rc == 0
+            outs[t].append((i % nslots, bytes(pr.a) + bytes(pr.b) + bytes(pr.c)))
+    for t in range(nthreads):   # warm-up
+        provers[t].prove_staged_raw(0, r, s, amd.Proof(), ctypes.create_string_buffer(max(1, args.n_public * 32)))
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    ths = [threading.Thread(target=work, args=(t,)) for t in range(nthreads)]
+    for th in ths:
+        th.start()
+    for th in ths:
+        th.join()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    # same witness slot => same proof bytes whichever handle produced it
+    by_slot = {}
+    for lst in outs:
+        for slot, b in lst:
+            assert by_slot.setdefault(slot, b) == b, "handles disagree on a proof"
+    for pv in provers[1:]:
+        pv.close()
+    log(f"batch throughput: {total} proofs on {nthreads} handles in {dt * 1e3:.1f} ms")
+    return {"proofs_per_sec": round(total / dt, 3), "proofs": total, "resident_handles": nthreads,
+            "distinct_witnesses": nslots, "ms_per_proof": round(1e3 * dt / total, 3)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -155,6 +202,10 @@ def main():
     ap.add_argument("--task-len", type=int, default=0)
     ap.add_argument("--cpu-sample-div", type=int, default=1)
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--batch-streams", type=int, default=2,
+                    help="extra measurement at N=1: throughput mode of BASELINE config 3 (independent "
+                         "witnesses proved concurrently by this many resident prover handles); 0 = skip")
+    ap.add_argument("--batch-proofs", type=int, default=32)
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -194,6 +245,7 @@ def main():
     prover = amd.Prover(zkey, device=dev, shard_rank=rank if sharded else 0,
                         shard_count=world if sharded else 1, window_bits=args.window_bits,
                         task_len=args.task_len)
+    zkey_for_batch = zkey if (world == 1 and args.batch_streams > 1) else None
     if world > 1 or args.no_cpu:
         zkey = None
     info = prover.info
@@ -251,6 +303,10 @@ def main():
     proofs = K * (world if (world > 1 and not sharded) else 1)
     value = proofs / elapsed
 
+    batch = None
+    if world == 1 and args.batch_streams > 1:
+        batch = batch_leg(amd, args, zkey_for_batch, wtns, prover, r, s, log)
+        zkey_for_batch = None
     if rank == 0:
         proof_obj = amd.proof_to_obj(pr)
         pub_list = [str(int.from_bytes(pub.raw[i * 32:(i + 1) * 32], "little")) for i in range(args.n_public)]
@@ -287,6 +343,8 @@ def main():
                          "avg_launch_ms": round(ms_per_launch, 4),
                          "note": "integer-VALU bound (~1.4k v_mad_u64_u32 per 96-byte point), see DESIGN.md"},
         }
+        if batch is not None:
+            out["batch_throughput"] = batch
         if world == 1 and not args.no_cpu:
             gpu_bytes = bytes(pr.a) + bytes(pr.b) + bytes(pr.c)
             prover.close()

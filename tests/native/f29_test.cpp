@@ -87,6 +87,8 @@ int main() {
     const F29 A = f29_from_fq(a), B = f29_from_fq(b);
     CHECK(fp_eq(f29_to_fq(A), a));
     CHECK(fp_eq(f29_to_fq(f29_mul(A, B)), fp_mul(a, b)));
+    CHECK(fp_eq(f29_to_fq(f29_sqr(A)), fp_mul(a, a)));
+    CHECK(fp_eq(f29_to_fq(f29_sqr_mul(A, B, f29_add(A, B))), fp_add(fp_mul(a, a), fp_mul(b, fp_add(a, b)))));
     CHECK(fp_eq(f29_to_fq(f29_add(A, B)), fp_add(a, b)));
     CHECK(fp_eq(f29_to_fq(f29_sub<2>(A, B)), fp_sub(a, b)));
     CHECK(fp_eq(f29_to_fq(f29_neg<2>(A)), fp_neg(a)));
@@ -94,6 +96,7 @@ int main() {
     const F29 s = f29_add(f29_add(A, B), f29_add(A, B));
     const F29 d = f29_sub<8>(A, B);
     CHECK(fp_eq(f29_to_fq(f29_mul(s, d)), fp_mul(fp_dbl(fp_add(a, b)), fp_sub(a, b))));
+    CHECK(fp_eq(f29_to_fq(f29_sqr(d)), fp_mul(fp_sub(a, b), fp_sub(a, b))));
     CHECK(fp_eq(f29_to_fq(f29_mul2(A, B, s, d)), fp_add(fp_mul(a, b), fp_mul(fp_dbl(fp_add(a, b)), fp_sub(a, b)))));
     CHECK(f29_is_zero(f29_sub<2>(A, A)) && f29_maybe_zero<7>(f29_sub<6>(A, A)));
     CHECK(!f29_is_zero(f29_sub<2>(A, B)));

@@ -9,6 +9,8 @@ class F1:  # Fq: single-product Montgomery
         assert A < LIM and B < LIM, (A,B)
         return A*B*rho + 1
     @staticmethod
+    def sqr(A): return F1.mul(A, A)
+    @staticmethod
     def ksub(B): return ceil(B)
 class F2:  # Fq2: fused two-product reductions; neg inside uses K=ceil(bound)
     @staticmethod
@@ -19,6 +21,11 @@ class F2:  # Fq2: fused two-product reductions; neg inside uses K=ceil(bound)
         c0 = (A*B + K*B)*rho + 1
         c1 = 2*A*B*rho + 1
         return max(c0,c1)
+    @staticmethod
+    def sqr(A):
+        # c0 = mont(a0^2 + (8p - a1)*a1), c1 = mont(a0 * 2a1): same bounds as the general product
+        assert 2*A < LIM
+        return F2.mul(A, A)
     @staticmethod
     def ksub(B): return ceil(B)
 def sub(F, A, B, K=None):
@@ -34,7 +41,7 @@ def run(F, name):
         # ---- madd
         U2 = F.mul(qx, BZ); S2 = F.mul(qy, BZ)
         P, ks['madd_P'] = sub(F, U2, BX); R, ks['madd_R'] = sub(F, S2, BY)
-        PP = F.mul(P,P); PPP = F.mul(P,PP); Qv = F.mul(BX,PP); RR = F.mul(R,R)
+        PP = F.sqr(P); PPP = F.mul(P,PP); Qv = F.mul(BX,PP); RR = F.sqr(R)
         s = PPP + 2*Qv
         X3, ks['X3'] = sub(F, RR, s)
         d, ks['QmX3'] = sub(F, Qv, X3)
@@ -44,15 +51,15 @@ def run(F, name):
         # ---- full add (both inputs with acc bounds)
         U1 = F.mul(BX,BZ); S1 = F.mul(BY,BZ)
         Pa, ks['add_P'] = sub(F, U1, U1); Ra, ks['add_R'] = sub(F, S1, S1)
-        PPa = F.mul(Pa,Pa); PPPa = F.mul(Pa,PPa); Qa = F.mul(U1,PPa); RRa = F.mul(Ra,Ra)
+        PPa = F.sqr(Pa); PPPa = F.mul(Pa,PPa); Qa = F.mul(U1,PPa); RRa = F.sqr(Ra)
         sa = PPPa + 2*Qa
         X3a, ks['aX3'] = sub(F, RRa, sa)
         da, ks['aQmX3'] = sub(F, Qa, X3a)
         Y3a, ks['aY3'] = sub(F, F.mul(Ra,da), F.mul(S1,PPPa))
         ZZa = F.mul(F.mul(BZ,BZ),PPa); ZZZa = F.mul(F.mul(BZ,BZ),PPPa)
         # ---- dbl
-        U = 2*BY; V = F.mul(U,U); W = F.mul(U,V); S = F.mul(BX,V); X2 = F.mul(BX,BX); M = 3*X2
-        X3d, ks['dX3'] = sub(F, F.mul(M,M), 2*S)
+        U = 2*BY; V = F.sqr(U); W = F.mul(U,V); S = F.mul(BX,V); X2 = F.sqr(BX); M = 3*X2
+        X3d, ks['dX3'] = sub(F, F.sqr(M), 2*S)
         dd, ks['dSmX3'] = sub(F, S, X3d)
         Y3d, ks['dY3'] = sub(F, F.mul(M,dd), F.mul(W,BY))
         ZZd = F.mul(V,BZ); ZZZd = F.mul(W,BZ)
