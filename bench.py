@@ -317,6 +317,17 @@ def main():
         bytes_per_launch = sum(96.0 * n for n, _ in launches) / max(1, len(launches))
         ms_per_launch = sum(ms for _, ms in launches) / max(1, len(launches))
         achieved = bytes_per_launch / (ms_per_launch * 1e-3) / 1e9 if ms_per_launch > 0 else 0.0
+        # HBM traffic of that kernel from the PMC passes committed under profiles/ (bench.py cannot
+        # collect counters itself); null when the file is missing or the workload differs
+        traffic, traffic_note = None, "no PMC summary for this workload"
+        try:
+            pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
+            if args.n_vars == 1_700_000 and args.n_constraints == 1_700_000:
+                traffic = pm["avg_traffic_bytes_per_launch"]
+                traffic_note = ("rocprofv3 FETCH_SIZE + WRITE_SIZE per launch, profiles/r01_pmc_traffic.json "
+                                "(separate --pmc passes, raw counters: see its 'method')")
+        except Exception:
+            pass
         nn, N, k = info.n_vars, info.domain_size, info.n_coefs
         b_proof = 44 * k + 384 * nn + 512 * N - 64 * (info.n_public + 1)
         out = {
@@ -338,10 +349,16 @@ def main():
             "proof_hbm_GBps": round(b_proof / (acc["total_ms"] / K * 1e-3) / 1e9, 2) if acc["total_ms"] else None,
             "roofline": {"bound": "hbm", "kernel": "msm_accumulate_kernel<G1> (avg over the A,B1,C,H launches)",
                          "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_note": traffic_note,
                          "algorithmic_bytes_per_launch": round(bytes_per_launch),
                          "avg_launch_ms": round(ms_per_launch, 4),
-                         "note": "integer-VALU bound (~1.4k v_mad_u64_u32 per 96-byte point), see DESIGN.md"},
+                         "int_roofline": {
+                             "kernel": "H-MSM accumulate launch (uniform 254-bit scalars)",
+                             "achieved_Tmad_per_s": round(info.n_h * 16 * 1750 / max(1e-9, acc["accum"][4] / K * 1e-3) / 1e12, 3),
+                             "peak_Tmad_per_s": 28.6,
+                             "note": "v_mad_u64_u32 count = points x 16 window digits x ~1750 mads per mixed addition; "
+                                     "peak = 256 CU x 4 SIMD x 64 lanes x 2.4 GHz / 5.5 cycles (tools/microbench.hip)"},
+                         "note": "integer-VALU bound: ~3.4k VALU instructions (1.75k v_mad_u64_u32) per mixed addition, 16 additions per 96-byte point; see DESIGN.md 3.3"},
         }
         if batch is not None:
             out["batch_throughput"] = batch

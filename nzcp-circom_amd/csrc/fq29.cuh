@@ -335,6 +335,48 @@ G16_HD Fq f29_to_fq(const F29& a) {
   return r;
 }
 
+// Optional out-of-line copies for the device loops (-DG16_F29_CALLS): fully inlined, one mixed
+// addition is ~5.5k instructions (~40 KiB).  Measured on MI355X (r01): calls are NOT faster (serial
+// proof 17.5 ms vs 16.3 ms inlined) -- the loop is bound by VALU issue (~3.4k instructions x ~5
+// cycles per wave-iteration, profiles/r01_pmc_accumulate.txt), not by instruction fetch.  The
+// variant stays because it cuts the G2 compile time by a third.
+#if defined(__HIP_DEVICE_COMPILE__) && defined(G16_F29_CALLS)
+// limbs travel as scalar arguments so that the ABI keeps them in VGPRs (two by-value structs spill
+// the second one to scratch)
+#define G16_L9(p) uint32_t p##0, uint32_t p##1, uint32_t p##2, uint32_t p##3, uint32_t p##4, uint32_t p##5, \
+                  uint32_t p##6, uint32_t p##7, uint32_t p##8
+#define G16_MK9(v, p) F29 v; v.l[0] = p##0; v.l[1] = p##1; v.l[2] = p##2; v.l[3] = p##3; v.l[4] = p##4; \
+                      v.l[5] = p##5; v.l[6] = p##6; v.l[7] = p##7; v.l[8] = p##8; v.pad_ = 0
+#define G16_X9(x) x.l[0], x.l[1], x.l[2], x.l[3], x.l[4], x.l[5], x.l[6], x.l[7], x.l[8]
+__device__ __noinline__ F29 f29_mul_raw(G16_L9(a), G16_L9(b)) { G16_MK9(A, a); G16_MK9(B, b); return f29_mul(A, B); }
+__device__ __noinline__ F29 f29_sqr_raw(G16_L9(a)) { G16_MK9(A, a); return f29_sqr(A); }
+__device__ __noinline__ F29 f29_mul2_raw(G16_L9(a), G16_L9(b), G16_L9(c), G16_L9(d)) {
+  G16_MK9(A, a); G16_MK9(B, b); G16_MK9(Cc, c); G16_MK9(D, d);
+  return f29_mul2(A, B, Cc, D);
+}
+__device__ __noinline__ F29 f29_sqr_mul_raw(G16_L9(a), G16_L9(c), G16_L9(d)) {
+  G16_MK9(A, a); G16_MK9(Cc, c); G16_MK9(D, d);
+  return f29_sqr_mul(A, Cc, D);
+}
+__device__ __forceinline__ F29 f29_mul_call(const F29& a, const F29& b) { return f29_mul_raw(G16_X9(a), G16_X9(b)); }
+__device__ __forceinline__ F29 f29_sqr_call(const F29& a) { return f29_sqr_raw(G16_X9(a)); }
+__device__ __forceinline__ F29 f29_mul2_call(const F29& a, const F29& b, const F29& c, const F29& d) {
+  return f29_mul2_raw(G16_X9(a), G16_X9(b), G16_X9(c), G16_X9(d));
+}
+__device__ __forceinline__ F29 f29_sqr_mul_call(const F29& a, const F29& c, const F29& d) {
+  return f29_sqr_mul_raw(G16_X9(a), G16_X9(c), G16_X9(d));
+}
+#define G16_F29_MUL(a, b) f29_mul_call(a, b)
+#define G16_F29_SQR(a) f29_sqr_call(a)
+#define G16_F29_MUL2(a, b, c, d) f29_mul2_call(a, b, c, d)
+#define G16_F29_SQR_MUL(a, c, d) f29_sqr_mul_call(a, c, d)
+#else
+#define G16_F29_MUL(a, b) f29_mul(a, b)
+#define G16_F29_SQR(a) f29_sqr(a)
+#define G16_F29_MUL2(a, b, c, d) f29_mul2(a, b, c, d)
+#define G16_F29_SQR_MUL(a, c, d) f29_sqr_mul(a, c, d)
+#endif
+
 // ------------------------------------------------------------------ Fq2 over F29
 struct alignas(8) F29x2 {
   F29 a, b;  // a + b*u, u^2 = -1
@@ -354,8 +396,8 @@ struct Fq29Ops {
   static G16_HD T add(const T& x, const T& y) { return f29_add(x, y); }
   template <int K> static G16_HD T sub(const T& x, const T& y) { return f29_sub<K>(x, y); }
   template <int K> static G16_HD T neg(const T& x) { return f29_neg<K>(x); }
-  static G16_HD T mul(const T& x, const T& y) { return f29_mul(x, y); }
-  static G16_HD T sqr(const T& x) { return f29_sqr(x); }
+  static G16_HD T mul(const T& x, const T& y) { return G16_F29_MUL(x, y); }
+  static G16_HD T sqr(const T& x) { return G16_F29_SQR(x); }
   static G16_HD T from_canon(const Fq& x) { return f29_from_fq(x); }
   static G16_HD Fq to_canon(const T& x) { return f29_to_fq(x); }
 };
@@ -380,11 +422,11 @@ struct Fq2x29Ops {
   // (a0 b0 - a1 b1) + (a0 b1 + a1 b0) u, two fused reductions; components of x below 8p
   static G16_HD T mul(const T& x, const T& y) {
     const F29 nb = f29_neg<8>(x.b);
-    return T{f29_mul2(x.a, y.a, nb, y.b), f29_mul2(x.a, y.b, x.b, y.a)};
+    return T{G16_F29_MUL2(x.a, y.a, nb, y.b), G16_F29_MUL2(x.a, y.b, x.b, y.a)};
   }
   // (a^2 - b^2) + (2ab) u: one fused square+product reduction and one single product
   static G16_HD T sqr(const T& x) {
-    return T{f29_sqr_mul(x.a, f29_neg<8>(x.b), x.b), f29_mul(x.a, f29_dbl(x.b))};
+    return T{G16_F29_SQR_MUL(x.a, f29_neg<8>(x.b), x.b), G16_F29_MUL(x.a, f29_dbl(x.b))};
   }
   static G16_HD T from_canon(const Fq2& x) { return T{f29_from_fq(x.a), f29_from_fq(x.b)}; }
   static G16_HD Fq2 to_canon(const T& x) { return Fq2{f29_to_fq(x.a), f29_to_fq(x.b)}; }

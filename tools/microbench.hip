@@ -11,9 +11,9 @@
 #define CHAINS 8
 #define ITERS 2048
 
-enum { OP_MAD_U64_U32, OP_MUL_LO, OP_MUL_HI, OP_MAD_U32_U24, OP_MUL_HI_U24, OP_ADD_CO, OP_LSHL_ADD_U64, OP_FMA_F64,
+enum { OP_MAD_DISTINCT, OP_MAD_DISTINCT_2CH, OP_LSHR_B64, OP_F29_MUL_LIKE, OP_MAD_U64_U32, OP_MUL_LO, OP_MUL_HI, OP_MAD_U32_U24, OP_MUL_HI_U24, OP_ADD_CO, OP_LSHL_ADD_U64, OP_FMA_F64,
        OP_ADD_U32, OP_MAD_U64_U32_C, OP_COUNT };
-static const char* kNames[] = {"v_mad_u64_u32 (asm)", "v_mul_lo_u32", "v_mul_hi_u32", "v_mad_u32_u24", "v_mul_hi_u32_u24",
+static const char* kNames[] = {"v_mad_u64_u32 distinct srcs, 8 chains", "v_mad_u64_u32 distinct srcs, 2 chains", "v_lshrrev_b64", "81-mad column product (C, 2 chains)", "v_mad_u64_u32 (asm)", "v_mul_lo_u32", "v_mul_hi_u32", "v_mad_u32_u24", "v_mul_hi_u32_u24",
                                "v_add_co_u32+v_addc_co_u32 (pair)", "v_lshl_add_u64", "v_fma_f64", "v_add_u32",
                                "(u64)a*b+c in C"};
 
@@ -29,7 +29,24 @@ __global__ __launch_bounds__(256) void bench(uint64_t* out, uint32_t a0, uint32_
   for (int it = 0; it < ITERS; it++) {
 #pragma unroll
     for (int k = 0; k < CHAINS; k++) {
-      if (OP == OP_MAD_U64_U32) {
+      if (OP == OP_MAD_DISTINCT) {
+        uint64_t cy;
+        asm volatile("v_mad_u64_u32 %0, %1, %2, %3, %0" : "+v"(acc[k]), "=s"(cy) : "v"(x[k]), "v"(x[(k + 3) & 7]));
+      } else if (OP == OP_MAD_DISTINCT_2CH) {
+        uint64_t cy;
+        asm volatile("v_mad_u64_u32 %0, %1, %2, %3, %0" : "+v"(acc[k & 1]), "=s"(cy) : "v"(x[k]), "v"(x[(k + 3) & 7]));
+      } else if (OP == OP_LSHR_B64) {
+        asm volatile("v_lshrrev_b64 %0, 29, %0" : "+v"(acc[k]));
+      } else if (OP == OP_F29_MUL_LIKE) {
+        // one "column" per k: 9 products into two accumulators, like fq29.cuh
+        uint64_t ab = 0, mp = acc[k];
+#pragma unroll
+        for (int i = 0; i < 5; i++) ab += (uint64_t)x[i] * x[7 - i];
+#pragma unroll
+        for (int i = 0; i < 4; i++) mp += (uint64_t)x[(i + k) & 7] * (0x12345u + i);
+        acc[k] = (ab + mp) >> 29;
+        x[k] = (uint32_t)acc[k] & 0x1fffffffu;
+      } else if (OP == OP_MAD_U64_U32) {
         uint64_t cy;
         asm volatile("v_mad_u64_u32 %0, %1, %2, %3, %0" : "+v"(acc[k]), "=s"(cy) : "v"(a), "v"(b));
       } else if (OP == OP_MUL_LO) {
@@ -92,6 +109,10 @@ int main() {
   printf("device %s, %d CUs, clock %.2f GHz (cycles below assume this clock)\n", prop.gcnArchName, prop.multiProcessorCount, ghz);
   uint64_t* dout;
   hipMalloc(&dout, sizeof(uint64_t) * 256 * 256 * 8);
+  run_one<OP_MAD_DISTINCT>(dout, ghz);
+  run_one<OP_MAD_DISTINCT_2CH>(dout, ghz);
+  run_one<OP_LSHR_B64>(dout, ghz);
+  run_one<OP_F29_MUL_LIKE>(dout, ghz);
   run_one<OP_MAD_U64_U32>(dout, ghz);
   run_one<OP_MAD_U64_U32_C>(dout, ghz);
   run_one<OP_MUL_LO>(dout, ghz);
