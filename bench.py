@@ -322,7 +322,7 @@ def main():
         traffic, traffic_note = None, "no PMC summary for this workload"
         try:
             pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
-            if args.n_vars == 1_700_000 and args.n_constraints == 1_700_000:
+            if world == 1 and args.n_vars == 1_700_000 and args.n_constraints == 1_700_000:
                 traffic = pm["avg_traffic_bytes_per_launch"]
                 traffic_note = ("rocprofv3 FETCH_SIZE + WRITE_SIZE per launch, profiles/r01_pmc_traffic.json "
                                 "(separate --pmc passes, raw counters: see its 'method')")

@@ -16,11 +16,16 @@ static int msm_convert_bases_g1(const void* in, void* out, uint32_t n) {
 }
 
 static int choose_c(uint32_t n) {
-  // minimise W * (n + 2.5 * 2^(c-1)) over c in [4, 16], W = ceil(256 / c)
-  int best = 4;
+  // minimise W * (n + 2.5 * 2^(c-1)) over c in [4, 16], W = ceil(256 / c).  For large n skip window
+  // sizes whose TOP window holds only 1..5 bits of the 254-bit scalar (c = 14, 12, 11, 10, 9, 7, 6, 4):
+  // its handful of buckets would each collect n / 2^bits entries (r01 sweep: c = 14 made the H-MSM 3x
+  // slower).  c = 16 (14 top bits), 15 (top window empty), 13 (7 bits) and 8 (6 bits) remain.
+  int best = 16;
   double best_cost = 1e300;
   for (int c = 4; c <= 16; c++) {
     const int W = (256 + c - 1) / c;
+    const int top_bits = 254 - c * (W - 1);
+    if (n >= 4096 && top_bits > 0 && top_bits < 6) continue;
     const double cost = (double)W * ((double)n + 2.5 * (double)(1u << (c - 1)));
     if (cost < best_cost) { best_cost = cost; best = c; }
   }
