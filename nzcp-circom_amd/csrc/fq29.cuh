@@ -31,23 +31,35 @@ struct alignas(8) F29 {   // 9 limbs + 1 pad word: 40 bytes, so points are 16-by
 
 static constexpr uint32_t kM29 = 0x1fffffffu;
 
+template <int K> struct Fq29KP;
 struct Fq29C {
   static constexpr uint32_t P[9] = G16_FQ29_P;
   static constexpr uint32_t ONE[9] = G16_FQ29_ONE;
   static constexpr uint32_t TO[9] = G16_FQ29_TO;
   static constexpr uint32_t FROM[9] = G16_FQ29_FROM;
   static constexpr uint32_t INV = G16_FQ29_INV;
+  template <int K> using KP = Fq29KP<K>;
 };
-template <int K> struct Fq29KP;
+template <int K> struct Fr29KP;
 #define G16_DEF_KP(k) \
-  template <> struct Fq29KP<k> { static constexpr uint32_t V[9] = G16_FQ29_KP##k; };
+  template <> struct Fq29KP<k> { static constexpr uint32_t V[9] = G16_FQ29_KP##k; }; \
+  template <> struct Fr29KP<k> { static constexpr uint32_t V[9] = G16_FR29_KP##k; };
 G16_DEF_KP(1) G16_DEF_KP(2) G16_DEF_KP(3) G16_DEF_KP(4) G16_DEF_KP(5) G16_DEF_KP(6) G16_DEF_KP(7) G16_DEF_KP(8)
 #undef G16_DEF_KP
+// the same format for the scalar field (QAP / NTT kernels, fr29.cuh)
+struct Fr29C {
+  static constexpr uint32_t P[9] = G16_FR29_P;
+  static constexpr uint32_t ONE[9] = G16_FR29_ONE;
+  static constexpr uint32_t TO[9] = G16_FR29_TO;
+  static constexpr uint32_t FROM[9] = G16_FR29_FROM;
+  static constexpr uint32_t INV = G16_FR29_INV;
+  template <int K> using KP = Fr29KP<K>;
+};
 
 #if defined(G16_F29_CHECK) && !defined(__HIP_DEVICE_COMPILE__)
 #include <assert.h>
 // host test build: every result must be below 16p (top limb comparison is enough: 16p < 2^258)
-#define G16_F29_ASSERT_BOUND(x) assert((x).l[8] < (16u * Fq29C::P[8] + 16u))
+#define G16_F29_ASSERT_BOUND(x) assert((x).l[8] < (16u * C::P[8] + 16u))
 #define G16_F29_ASSERT_LIMBS(x) do { for (int _i = 0; _i < 8; _i++) assert((x).l[_i] <= kM29); } while (0)
 #else
 #define G16_F29_ASSERT_BOUND(x) ((void)0)
@@ -60,10 +72,10 @@ G16_HD F29 f29_zero() {
   for (int i = 0; i < 9; i++) r.l[i] = 0;
   return r;
 }
-G16_HD F29 f29_one() {
+template <class C = Fq29C> G16_HD F29 f29_one() {
   F29 r;
 #pragma unroll
-  for (int i = 0; i < 9; i++) r.l[i] = Fq29C::ONE[i];
+  for (int i = 0; i < 9; i++) r.l[i] = C::ONE[i];
   return r;
 }
 
@@ -79,7 +91,7 @@ G16_HD void f29_carry(F29& a) {
   a.l[8] += c;
 }
 
-G16_HD F29 f29_add(const F29& a, const F29& b) {
+template <class C = Fq29C> G16_HD F29 f29_add(const F29& a, const F29& b) {
   F29 r;
 #pragma unroll
   for (int i = 0; i < 9; i++) r.l[i] = a.l[i] + b.l[i];
@@ -87,21 +99,21 @@ G16_HD F29 f29_add(const F29& a, const F29& b) {
   G16_F29_ASSERT_BOUND(r);
   return r;
 }
-G16_HD F29 f29_dbl(const F29& a) { return f29_add(a, a); }
+template <class C = Fq29C> G16_HD F29 f29_dbl(const F29& a) { return f29_add<C>(a, a); }
 
 // a + K*p - b; requires value(b) <= K*p
-template <int K> G16_HD F29 f29_sub(const F29& a, const F29& b) {
+template <int K, class C = Fq29C> G16_HD F29 f29_sub(const F29& a, const F29& b) {
   F29 r;
 #pragma unroll
-  for (int i = 0; i < 9; i++) r.l[i] = a.l[i] + Fq29KP<K>::V[i] - b.l[i];
+  for (int i = 0; i < 9; i++) r.l[i] = a.l[i] + C::template KP<K>::V[i] - b.l[i];
   f29_carry(r);
   G16_F29_ASSERT_BOUND(r);
   return r;
 }
-template <int K> G16_HD F29 f29_neg(const F29& b) {
+template <int K, class C = Fq29C> G16_HD F29 f29_neg(const F29& b) {
   F29 r;
 #pragma unroll
-  for (int i = 0; i < 9; i++) r.l[i] = Fq29KP<K>::V[i] - b.l[i];
+  for (int i = 0; i < 9; i++) r.l[i] = C::template KP<K>::V[i] - b.l[i];
   f29_carry(r);
   return r;
 }
@@ -111,7 +123,7 @@ template <int K> G16_HD F29 f29_neg(const F29& b) {
 // The a*b terms and the m*p terms of a column go to two independent 64-bit accumulators (each
 // < 2^63), so a wave that is alone on its SIMD (the reduce kernels, G2) has two mad chains in
 // flight instead of one 162-long dependency chain (measured: 12 cycles/mad dependent vs 5.5 issue).
-G16_HD F29 f29_mul(const F29& a, const F29& b) {
+template <class C = Fq29C> G16_HD F29 f29_mul(const F29& a, const F29& b) {
   G16_F29_ASSERT_LIMBS(a); G16_F29_ASSERT_LIMBS(b);
   uint64_t carry = 0;
   uint32_t m[9];
@@ -122,10 +134,10 @@ G16_HD F29 f29_mul(const F29& a, const F29& b) {
 #pragma unroll
     for (int i = 0; i <= k; i++) ab += (uint64_t)a.l[i] * b.l[k - i];
 #pragma unroll
-    for (int i = 0; i < k; i++) mp += (uint64_t)m[i] * Fq29C::P[k - i];
+    for (int i = 0; i < k; i++) mp += (uint64_t)m[i] * C::P[k - i];
     uint64_t acc = ab + mp;
-    m[k] = ((uint32_t)acc * Fq29C::INV) & kM29;
-    acc += (uint64_t)m[k] * Fq29C::P[0];
+    m[k] = ((uint32_t)acc * C::INV) & kM29;
+    acc += (uint64_t)m[k] * C::P[0];
     carry = acc >> 29;
   }
 #pragma unroll
@@ -134,7 +146,7 @@ G16_HD F29 f29_mul(const F29& a, const F29& b) {
 #pragma unroll
     for (int i = k - 8; i <= 8; i++) ab += (uint64_t)a.l[i] * b.l[k - i];
 #pragma unroll
-    for (int i = k - 8; i <= 8; i++) mp += (uint64_t)m[i] * Fq29C::P[k - i];
+    for (int i = k - 8; i <= 8; i++) mp += (uint64_t)m[i] * C::P[k - i];
     const uint64_t acc = ab + mp;
     r.l[k - 9] = (uint32_t)acc & kM29;
     carry = acc >> 29;
@@ -145,7 +157,7 @@ G16_HD F29 f29_mul(const F29& a, const F29& b) {
 }
 // a^2 / 2^261: the cross terms a_i a_j (i < j) are taken once against the doubled limb 2 a_i, so
 // 45 product terms instead of 81 (a column still sums below 2^63: 4 * 2^59 + 2^58 + 9 * 2^58).
-G16_HD F29 f29_sqr(const F29& a) {
+template <class C = Fq29C> G16_HD F29 f29_sqr(const F29& a) {
   G16_F29_ASSERT_LIMBS(a);
   uint32_t a2[9];
 #pragma unroll
@@ -165,14 +177,14 @@ G16_HD F29 f29_sqr(const F29& a) {
     }
     if (k < 9) {
 #pragma unroll
-      for (int i = 0; i < k; i++) mp += (uint64_t)m[i] * Fq29C::P[k - i];
+      for (int i = 0; i < k; i++) mp += (uint64_t)m[i] * C::P[k - i];
       uint64_t acc = ab + mp;
-      m[k] = ((uint32_t)acc * Fq29C::INV) & kM29;
-      acc += (uint64_t)m[k] * Fq29C::P[0];
+      m[k] = ((uint32_t)acc * C::INV) & kM29;
+      acc += (uint64_t)m[k] * C::P[0];
       carry = acc >> 29;
     } else {
 #pragma unroll
-      for (int i = k - 8; i <= 8; i++) mp += (uint64_t)m[i] * Fq29C::P[k - i];
+      for (int i = k - 8; i <= 8; i++) mp += (uint64_t)m[i] * C::P[k - i];
       const uint64_t acc = ab + mp;
       r.l[k - 9] = (uint32_t)acc & kM29;
       carry = acc >> 29;
@@ -183,7 +195,7 @@ G16_HD F29 f29_sqr(const F29& a) {
   return r;
 }
 // (a^2 + c*d) / 2^261 with one reduction (real part of an Fq2 square)
-G16_HD F29 f29_sqr_mul(const F29& a, const F29& c, const F29& d) {
+template <class C = Fq29C> G16_HD F29 f29_sqr_mul(const F29& a, const F29& c, const F29& d) {
   uint32_t a2[9];
 #pragma unroll
   for (int i = 0; i < 9; i++) a2[i] = a.l[i] << 1;
@@ -203,14 +215,14 @@ G16_HD F29 f29_sqr_mul(const F29& a, const F29& c, const F29& d) {
     }
     if (k < 9) {
 #pragma unroll
-      for (int i = 0; i < k; i++) mp += (uint64_t)m[i] * Fq29C::P[k - i];
+      for (int i = 0; i < k; i++) mp += (uint64_t)m[i] * C::P[k - i];
       uint64_t acc = ab + cd + mp;
-      m[k] = ((uint32_t)acc * Fq29C::INV) & kM29;
-      acc += (uint64_t)m[k] * Fq29C::P[0];
+      m[k] = ((uint32_t)acc * C::INV) & kM29;
+      acc += (uint64_t)m[k] * C::P[0];
       carry = acc >> 29;
     } else {
 #pragma unroll
-      for (int i = k - 8; i <= 8; i++) mp += (uint64_t)m[i] * Fq29C::P[k - i];
+      for (int i = k - 8; i <= 8; i++) mp += (uint64_t)m[i] * C::P[k - i];
       const uint64_t acc = ab + cd + mp;
       r.l[k - 9] = (uint32_t)acc & kM29;
       carry = acc >> 29;
@@ -223,7 +235,7 @@ G16_HD F29 f29_sqr_mul(const F29& a, const F29& c, const F29& d) {
 
 // (a*b + c*d) / 2^261 with ONE reduction (Fq2 products): 27 terms < 2^58 per column still fit
 // (three independent accumulators: a*b, c*d, m*p).
-G16_HD F29 f29_mul2(const F29& a, const F29& b, const F29& c, const F29& d) {
+template <class C = Fq29C> G16_HD F29 f29_mul2(const F29& a, const F29& b, const F29& c, const F29& d) {
   uint64_t carry = 0;
   uint32_t m[9];
   F29 r;
@@ -236,10 +248,10 @@ G16_HD F29 f29_mul2(const F29& a, const F29& b, const F29& c, const F29& d) {
       cd += (uint64_t)c.l[i] * d.l[k - i];
     }
 #pragma unroll
-    for (int i = 0; i < k; i++) mp += (uint64_t)m[i] * Fq29C::P[k - i];
+    for (int i = 0; i < k; i++) mp += (uint64_t)m[i] * C::P[k - i];
     uint64_t acc = ab + cd + mp;
-    m[k] = ((uint32_t)acc * Fq29C::INV) & kM29;
-    acc += (uint64_t)m[k] * Fq29C::P[0];
+    m[k] = ((uint32_t)acc * C::INV) & kM29;
+    acc += (uint64_t)m[k] * C::P[0];
     carry = acc >> 29;
   }
 #pragma unroll
@@ -251,7 +263,7 @@ G16_HD F29 f29_mul2(const F29& a, const F29& b, const F29& c, const F29& d) {
       cd += (uint64_t)c.l[i] * d.l[k - i];
     }
 #pragma unroll
-    for (int i = k - 8; i <= 8; i++) mp += (uint64_t)m[i] * Fq29C::P[k - i];
+    for (int i = k - 8; i <= 8; i++) mp += (uint64_t)m[i] * C::P[k - i];
     const uint64_t acc = ab + cd + mp;
     r.l[k - 9] = (uint32_t)acc & kM29;
     carry = acc >> 29;
@@ -269,30 +281,30 @@ G16_HD bool f29_is_literal_zero(const F29& a) {
   return o == 0;
 }
 // x == 0 (mod p), exact, for any x below 16p: x/2^261 mod p lands in [0, p]
-G16_HD bool f29_is_zero(const F29& a) {
+template <class C = Fq29C> G16_HD bool f29_is_zero(const F29& a) {
   F29 one = f29_zero();
   one.l[0] = 1;
-  const F29 y = f29_mul(a, one);
+  const F29 y = f29_mul<C>(a, one);
   uint32_t z = 0, e = 0;
 #pragma unroll
-  for (int i = 0; i < 9; i++) { z |= y.l[i]; e |= y.l[i] ^ Fq29C::P[i]; }
+  for (int i = 0; i < 9; i++) { z |= y.l[i]; e |= y.l[i] ^ C::P[i]; }
   return z == 0 || e == 0;
 }
 // cheap necessary condition for x == 0 (mod p) when x < (KMAX+1)*p: the low limb is exact after
 // the carry ripple, and x = k*p forces it to k*p mod 2^29.
-template <int KMAX> G16_HD bool f29_maybe_zero(const F29& a) {
+template <int KMAX, class C = Fq29C> G16_HD bool f29_maybe_zero(const F29& a) {
   bool hit = false;
   uint32_t kp = 0;
 #pragma unroll
   for (int k = 0; k <= KMAX; k++) {
     hit |= (a.l[0] == (kp & kM29));
-    kp += Fq29C::P[0];
+    kp += C::P[0];
   }
   return hit;
 }
 
 // canonical 8 x 32 Montgomery(2^256) image <-> F29 Montgomery(2^261)
-G16_HD F29 f29_from_fq(const Fq& v) {
+template <class C = Fq29C, class PM = FqParams> G16_HD F29 f29_from_fq(const Fp<PM>& v) {
   F29 t;
 #pragma unroll
   for (int i = 0; i < 9; i++) {
@@ -303,26 +315,26 @@ G16_HD F29 f29_from_fq(const Fq& v) {
   }
   F29 c;
 #pragma unroll
-  for (int i = 0; i < 9; i++) c.l[i] = Fq29C::TO[i];
-  return f29_mul(t, c);
+  for (int i = 0; i < 9; i++) c.l[i] = C::TO[i];
+  return f29_mul<C>(t, c);
 }
-G16_HD Fq f29_to_fq(const F29& a) {
+template <class C = Fq29C, class PM = FqParams> G16_HD Fp<PM> f29_to_fq(const F29& a) {
   F29 c;
 #pragma unroll
-  for (int i = 0; i < 9; i++) c.l[i] = Fq29C::FROM[i];
-  F29 t = f29_mul(a, c);  // x * 2^256 mod p, in [0, p]
+  for (int i = 0; i < 9; i++) c.l[i] = C::FROM[i];
+  F29 t = f29_mul<C>(a, c);  // x * 2^256 mod p, in [0, p]
   // t >= p ? t - p : t   (limbs are exact)
   uint32_t d[9];
   int32_t br = 0;
 #pragma unroll
   for (int i = 0; i < 9; i++) {
-    const int32_t x = (int32_t)t.l[i] - (int32_t)Fq29C::P[i] + br;
+    const int32_t x = (int32_t)t.l[i] - (int32_t)C::P[i] + br;
     d[i] = (uint32_t)x & (i < 8 ? kM29 : 0xffffffffu);
     br = x >> 29;  // arithmetic shift: 0 or -1 (for i < 8)
     if (i == 8) br = x < 0 ? -1 : 0;
   }
   const bool ge = (br == 0);
-  Fq r;
+  Fp<PM> r;
 #pragma unroll
   for (int i = 0; i < 8; i++) r.v[i] = 0;
 #pragma unroll

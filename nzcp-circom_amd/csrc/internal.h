@@ -9,6 +9,7 @@
 
 #include "../../include/g16_prover.h"
 #include "ec.cuh"
+#include "fq29.cuh"
 
 namespace g16 {
 
@@ -31,9 +32,9 @@ struct NttPass { int lo_bits, S, tb; };
 struct NttTables {
   int L = -1;                // log2 N
   int tile_log = 0;
-  Fr* tw_fwd = nullptr;      // w_N^i, i < N/2 (Montgomery)
-  Fr* tw_inv = nullptr;      // w_N^-i
-  Fr* coset = nullptr;       // coset[j] = N^-1 * w_2N^bitrev(j)  (position order after the DIF iNTT)
+  F29* tw_fwd = nullptr;     // w_N^i, i < N/2 (9x29 lazy format, Montgomery 2^261)
+  F29* tw_inv = nullptr;     // w_N^-i
+  F29* coset = nullptr;      // coset[j] = N^-1 * w_2N^bitrev(j)  (position order after the DIF iNTT)
   std::vector<NttPass> passes;  // DIT order; DIF runs them reversed
 };
 int ntt_tables_create(NttTables& t, int L, hipStream_t st);
@@ -41,26 +42,30 @@ void ntt_tables_destroy(NttTables& t);
 // Batched in-place transforms over `nvec` vectors (device pointers in host array vecs).
 // dif_inverse: natural in -> bit-reversed out with w^-1 (no scaling);  dit_forward: bit-reversed
 // in -> natural out with w.
-int ntt_dif_inverse(const NttTables& t, Fr* const* vecs, int nvec, hipStream_t st);
-int ntt_dit_forward(const NttTables& t, Fr* const* vecs, int nvec, hipStream_t st);
+int ntt_dif_inverse(const NttTables& t, F29* const* vecs, int nvec, hipStream_t st);
+int ntt_dit_forward(const NttTables& t, F29* const* vecs, int nvec, hipStream_t st);
 // x[j] *= coset[j]  (fused 1/N and w_2N^i shift in bit-reversed position order)
-int ntt_coset_scale(const NttTables& t, Fr* const* vecs, int nvec, hipStream_t st);
-// x[j] *= N^-1, then bit-reverse permutation out-of-place helpers for the operator-level API
-int ntt_scale_bitrev(const NttTables& t, const Fr* in, Fr* out, bool scale_ninv, hipStream_t st);
-// P[i] = fromMontgomery(a[i]*b[i] - c[i])   (qap_joinABC + batchFromMontgomery)
-int ntt_join_abc(const Fr* a, const Fr* b, const Fr* c, Fr* p_std, size_t n, hipStream_t st);
+int ntt_coset_scale(const NttTables& t, F29* const* vecs, int nvec, hipStream_t st);
+// operator-level glue: canonical Montgomery(2^256) Fr image <-> the kernels' lazy format (optionally
+// through the bit-reversal permutation; export can fold in the 1/N of the inverse transform)
+int ntt_import(const NttTables& t, const Fr* in, F29* out, bool bitrev, hipStream_t st);
+int ntt_export(const NttTables& t, const F29* in, Fr* out, bool bitrev, bool scale_ninv, hipStream_t st);
+// P[i] = plain(a[i]*b[i] - c[i])   (qap_joinABC + batchFromMontgomery)
+int ntt_join_abc(const F29* a, const F29* b, const F29* c, Fr* p_std, size_t n, hipStream_t st);
 
 // ---------------------------------------------------------------- QAP (qap.hip)
 struct QapCsr {
   // CSR of zkey section 4 per matrix (0 = A, 1 = B): rows = domainSize
   uint32_t* row_ptr[2] = {nullptr, nullptr};  // [N+1]
   uint32_t* col[2] = {nullptr, nullptr};      // signal index per record
-  Fr* val[2] = {nullptr, nullptr};            // coef*R^2 as stored in the file
+  F29* val[2] = {nullptr, nullptr};           // coef * 2^522 (lazy format): one product with the plain witness word
   size_t nnz[2] = {0, 0};
   uint32_t N = 0;
 };
-// a[c] = sum val*w[col] (Montgomery), b likewise, cc = a*b; w is the standard-form witness
-int qap_eval(const QapCsr& q, const Fr* w_std, Fr* a, Fr* b, Fr* cc, hipStream_t st);
+// a[c] = sum val*w[col] (lazy Montgomery), b likewise, cc = a*b; w is the standard-form witness
+int qap_eval(const QapCsr& q, const Fr* w_std, F29* a, F29* b, F29* cc, hipStream_t st);
+// zkey section-4 words (device, canonical) -> the lazy coefficient format, once at create
+int qap_convert_coefs(const Fr* in, F29* out, size_t n, hipStream_t st);
 
 // ---------------------------------------------------------------- MSM (msm_g1.hip / msm_g2.hip)
 struct MsmConfig {

@@ -14,6 +14,13 @@
 // over HBM instead of 21.  Tiles of later passes are 2^S rows x T columns with T >= 4
 // contiguous elements (128 B runs) for coalescing.  Index math validated by the Python model in
 // tests/test_ntt_plan.py.
+//
+// Arithmetic: Fr in the 9 x 29-bit lazy format (fr29.cuh; 40-byte elements in HBM and LDS).  A
+// butterfly is one 162-mad product + a limb-wise add and sub; values drift upwards between
+// products, so every element is weak-reduced on load and after every 3rd DIF stage (sum branch
+// doubles: 1 -> 2 -> 4 -> 8r, subtraction offsets K = 2, 3, 5) or after the 7th DIT stage (+2r per
+// stage), keeping every product input below 16r.
+#include "fr29.cuh"
 #include "internal.h"
 
 namespace g16 {
@@ -22,17 +29,17 @@ static constexpr int kTileLogMax = 10;
 static constexpr int kMinTb = 2;
 static constexpr int kThreads = 256;
 
-struct VecPtrs { Fr* p[4]; };
+struct VecPtrs { F29* p[4]; };
 
 __device__ __forceinline__ uint32_t bitrev_dev(uint32_t x, int bits) {
   return bits == 0 ? 0u : (__brev(x) >> (32 - bits));
 }
 
-__global__ __launch_bounds__(kThreads) void ntt_pass_kernel(VecPtrs vecs, const Fr* __restrict__ tw,
+__global__ __launch_bounds__(kThreads) void ntt_pass_kernel(VecPtrs vecs, const F29* __restrict__ tw,
                                                             int L, int tile_log, int lo_bits, int S,
                                                             int tb, int dif) {
-  __shared__ Fr tile[1 << kTileLogMax];
-  Fr* __restrict__ x = vecs.p[blockIdx.y];
+  __shared__ F29 tile[1 << kTileLogMax];
+  F29* __restrict__ x = vecs.p[blockIdx.y];
   const uint32_t tile_n = 1u << tile_log;
   const uint32_t T = 1u << tb;
   const uint32_t t = blockIdx.x;
@@ -47,7 +54,7 @@ __global__ __launch_bounds__(kThreads) void ntt_pass_kernel(VecPtrs vecs, const 
   auto gidx = [&](uint32_t e) -> size_t {
     return base + ((size_t)(e >> tb) << lo_bits) + (e & (T - 1));
   };
-  for (uint32_t e = threadIdx.x; e < tile_n; e += kThreads) tile[e] = x[gidx(e)];
+  for (uint32_t e = threadIdx.x; e < tile_n; e += kThreads) tile[e] = fr29_weak_reduce(x[gidx(e)]);
   __syncthreads();
   for (int k = 0; k < S; k++) {
     const int st = dif ? (S - 1 - k) : k;
@@ -55,55 +62,68 @@ __global__ __launch_bounds__(kThreads) void ntt_pass_kernel(VecPtrs vecs, const 
     const int beta = lo_bits + st;  // global index bit this stage acts on
     const size_t hmask = ((size_t)1 << beta) - 1;
     const int sh = L - 1 - beta;
+    const int phase = k % 3;        // DIF: stages since the last weak reduction
     for (uint32_t bf = threadIdx.x; bf < (tile_n >> 1); bf += kThreads) {
       const uint32_t e0 = ((bf >> bit) << (bit + 1)) | (bf & ((1u << bit) - 1));
       const uint32_t e1 = e0 | (1u << bit);
-      const Fr w = tw[(gidx(e0) & hmask) << sh];
-      Fr u = tile[e0], v = tile[e1];
+      const F29 w = tw[(gidx(e0) & hmask) << sh];
+      const F29 u = tile[e0], v = tile[e1];
       if (dif) {
-        tile[e0] = fp_add(u, v);
-        tile[e1] = fp_mul(fp_sub(u, v), w);
+        tile[e0] = fr29_add(u, v);
+        const F29 d = phase == 0 ? fr29_sub<2>(u, v) : (phase == 1 ? fr29_sub<3>(u, v) : fr29_sub<5>(u, v));
+        tile[e1] = fr29_mul(d, w);
       } else {
-        v = fp_mul(v, w);
-        tile[e0] = fp_add(u, v);
-        tile[e1] = fp_sub(u, v);
+        const F29 tv = fr29_mul(v, w);
+        tile[e0] = fr29_add(u, tv);
+        tile[e1] = fr29_sub<2>(u, tv);
       }
     }
     __syncthreads();
+    const bool reduce_now = dif ? (phase == 2 && k + 1 < S) : (k == 6 && S > 7);
+    if (reduce_now) {
+      for (uint32_t e = threadIdx.x; e < tile_n; e += kThreads) tile[e] = fr29_weak_reduce(tile[e]);
+      __syncthreads();
+    }
   }
   for (uint32_t e = threadIdx.x; e < tile_n; e += kThreads) x[gidx(e)] = tile[e];
 }
 
 // tw[i] = w^i
-__global__ void ntt_pow_table_kernel(Fr* out, Fr w, size_t n) {
+__global__ void ntt_pow_table_kernel(F29* out, F29 w, size_t n) {
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) out[i] = fp_pow_u64(w, (uint64_t)i);
+  if (i < n) out[i] = fr29_pow_u64(w, (uint64_t)i);
 }
 // coset[j] = ninv * inc^bitrev(j)
-__global__ void ntt_coset_table_kernel(Fr* out, Fr inc, Fr ninv, int L) {
+__global__ void ntt_coset_table_kernel(F29* out, F29 inc, F29 ninv, int L) {
   size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (j < ((size_t)1 << L)) out[j] = fp_mul(ninv, fp_pow_u64(inc, (uint64_t)bitrev_dev((uint32_t)j, L)));
+  if (j < ((size_t)1 << L)) out[j] = fr29_mul(ninv, fr29_pow_u64(inc, (uint64_t)bitrev_dev((uint32_t)j, L)));
 }
-__global__ void ntt_scale_kernel(VecPtrs vecs, const Fr* __restrict__ tab, size_t n) {
+__global__ void ntt_scale_kernel(VecPtrs vecs, const F29* __restrict__ tab, size_t n) {
   size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (j < n) {
-    Fr* x = vecs.p[blockIdx.y];
-    x[j] = fp_mul(x[j], tab[j]);
+    F29* x = vecs.p[blockIdx.y];
+    x[j] = fr29_mul(x[j], tab[j]);
   }
 }
-__global__ void ntt_bitrev_kernel(const Fr* __restrict__ in, Fr* __restrict__ out, Fr ninv, int scale,
-                                  int L) {
+// operator-level API glue: canonical Montgomery(2^256) image <-> lazy format, with the bit reversal
+__global__ void ntt_import_bitrev_kernel(const Fr* __restrict__ in, F29* __restrict__ out, int bitrev, int L) {
+  size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (j < ((size_t)1 << L)) out[bitrev ? bitrev_dev((uint32_t)j, L) : j] = fr29_from_fr(in[j]);
+}
+__global__ void ntt_export_bitrev_kernel(const F29* __restrict__ in, Fr* __restrict__ out, F29 scale, int do_scale,
+                                         int bitrev, int L) {
   size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (j < ((size_t)1 << L)) {
-    Fr v = in[j];
-    if (scale) v = fp_mul(v, ninv);
-    out[bitrev_dev((uint32_t)j, L)] = v;
+    F29 v = in[j];
+    if (do_scale) v = fr29_mul(v, scale);
+    out[bitrev ? bitrev_dev((uint32_t)j, L) : j] = fr29_to_fr(v);
   }
 }
-__global__ void ntt_join_kernel(const Fr* __restrict__ a, const Fr* __restrict__ b,
-                                const Fr* __restrict__ c, Fr* __restrict__ p, size_t n) {
+// P[i] = a[i]*b[i] - c[i] as a plain (standard-form) integer: the H-MSM scalar
+__global__ void ntt_join_kernel(const F29* __restrict__ a, const F29* __restrict__ b,
+                                const F29* __restrict__ c, Fr* __restrict__ p, size_t n) {
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) p[i] = fp_from_mont(fp_sub(fp_mul(a[i], b[i]), c[i]));
+  if (i < n) p[i] = fr29_to_plain(fr29_sub<2>(fr29_mul(a[i], b[i]), fr29_weak_reduce(c[i])));
 }
 
 static Fr host_root(int L) {  // Fr.w[L] in Montgomery form
@@ -131,12 +151,13 @@ int ntt_tables_create(NttTables& t, int L, hipStream_t st) {
     done += S;
   }
   const size_t N = (size_t)1 << L, half = N > 1 ? N / 2 : 1;
-  G16_HIP(hipMalloc(&t.tw_fwd, half * sizeof(Fr)));
-  G16_HIP(hipMalloc(&t.tw_inv, half * sizeof(Fr)));
-  G16_HIP(hipMalloc(&t.coset, N * sizeof(Fr)));
-  const Fr w = host_root(L), winv = fp_inv(w);
-  const Fr inc = host_root(L + 1);  // w_2N (L <= 27 so L+1 <= 28)
-  const Fr ninv = fp_inv(host_from_u64(N));
+  G16_HIP(hipMalloc(&t.tw_fwd, half * sizeof(F29)));
+  G16_HIP(hipMalloc(&t.tw_inv, half * sizeof(F29)));
+  G16_HIP(hipMalloc(&t.coset, N * sizeof(F29)));
+  const Fr wc = host_root(L);
+  const F29 w = fr29_from_fr(wc), winv = fr29_from_fr(fp_inv(wc));
+  const F29 inc = fr29_from_fr(host_root(L + 1));  // w_2N (L <= 27 so L+1 <= 28)
+  const F29 ninv = fr29_from_fr(fp_inv(host_from_u64(N)));
   const int bs = 256;
   ntt_pow_table_kernel<<<(unsigned)((half + bs - 1) / bs), bs, 0, st>>>(t.tw_fwd, w, half);
   ntt_pow_table_kernel<<<(unsigned)((half + bs - 1) / bs), bs, 0, st>>>(t.tw_inv, winv, half);
@@ -153,7 +174,7 @@ void ntt_tables_destroy(NttTables& t) {
   t.L = -1;
 }
 
-static int run_passes(const NttTables& t, Fr* const* vecs, int nvec, bool dif, hipStream_t st) {
+static int run_passes(const NttTables& t, F29* const* vecs, int nvec, bool dif, hipStream_t st) {
   if (nvec < 1 || nvec > 4) { set_error("ntt: nvec must be 1..4"); return G16_E_ARG; }
   if (t.L == 0) return G16_OK;
   VecPtrs vp{};
@@ -170,14 +191,14 @@ static int run_passes(const NttTables& t, Fr* const* vecs, int nvec, bool dif, h
   return G16_OK;
 }
 
-int ntt_dif_inverse(const NttTables& t, Fr* const* vecs, int nvec, hipStream_t st) {
+int ntt_dif_inverse(const NttTables& t, F29* const* vecs, int nvec, hipStream_t st) {
   return run_passes(t, vecs, nvec, true, st);
 }
-int ntt_dit_forward(const NttTables& t, Fr* const* vecs, int nvec, hipStream_t st) {
+int ntt_dit_forward(const NttTables& t, F29* const* vecs, int nvec, hipStream_t st) {
   return run_passes(t, vecs, nvec, false, st);
 }
 
-int ntt_coset_scale(const NttTables& t, Fr* const* vecs, int nvec, hipStream_t st) {
+int ntt_coset_scale(const NttTables& t, F29* const* vecs, int nvec, hipStream_t st) {
   if (nvec < 1 || nvec > 4) { set_error("ntt: nvec must be 1..4"); return G16_E_ARG; }
   VecPtrs vp{};
   for (int i = 0; i < nvec; i++) vp.p[i] = vecs[i];
@@ -187,15 +208,22 @@ int ntt_coset_scale(const NttTables& t, Fr* const* vecs, int nvec, hipStream_t s
   return G16_OK;
 }
 
-int ntt_scale_bitrev(const NttTables& t, const Fr* in, Fr* out, bool scale_ninv, hipStream_t st) {
+int ntt_import(const NttTables& t, const Fr* in, F29* out, bool bitrev, hipStream_t st) {
   const size_t N = (size_t)1 << t.L;
-  const Fr ninv = fp_inv(host_from_u64(N));
-  ntt_bitrev_kernel<<<(unsigned)((N + 255) / 256), 256, 0, st>>>(in, out, ninv, scale_ninv ? 1 : 0, t.L);
+  ntt_import_bitrev_kernel<<<(unsigned)((N + 255) / 256), 256, 0, st>>>(in, out, bitrev ? 1 : 0, t.L);
+  G16_HIP(hipGetLastError());
+  return G16_OK;
+}
+int ntt_export(const NttTables& t, const F29* in, Fr* out, bool bitrev, bool scale_ninv, hipStream_t st) {
+  const size_t N = (size_t)1 << t.L;
+  const F29 ninv = fr29_from_fr(fp_inv(host_from_u64(N)));
+  ntt_export_bitrev_kernel<<<(unsigned)((N + 255) / 256), 256, 0, st>>>(in, out, ninv, scale_ninv ? 1 : 0,
+                                                                        bitrev ? 1 : 0, t.L);
   G16_HIP(hipGetLastError());
   return G16_OK;
 }
 
-int ntt_join_abc(const Fr* a, const Fr* b, const Fr* c, Fr* p_std, size_t n, hipStream_t st) {
+int ntt_join_abc(const F29* a, const F29* b, const F29* c, Fr* p_std, size_t n, hipStream_t st) {
   ntt_join_kernel<<<(unsigned)((n + 255) / 256), 256, 0, st>>>(a, b, c, p_std, n);
   G16_HIP(hipGetLastError());
   return G16_OK;

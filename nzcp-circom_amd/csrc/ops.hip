@@ -138,15 +138,19 @@ static int fft_impl(int device, uint8_t* buf, size_t n, bool inverse) {
   if (!rc) rc = dx.alloc(n * 32);
   if (!rc) rc = dy.alloc(n * 32);
   if (!rc && hipMemcpyAsync(dx.p, buf, n * 32, hipMemcpyHostToDevice, st) != hipSuccess) { set_error("hipMemcpy failed"); rc = G16_E_HIP; }
-  Fr* vx[1] = {(Fr*)dx.p};
-  Fr* vy[1] = {(Fr*)dy.p};
+  // dx: canonical image (in, then out); dz: the lazy working vector
+  DevBuf dz;
+  if (!rc) rc = dz.alloc(n * sizeof(F29));
+  F29* vz[1] = {(F29*)dz.p};
   if (!rc) {
     if (inverse) {
-      rc = ntt_dif_inverse(t, vx, 1, st);
-      if (!rc) rc = ntt_scale_bitrev(t, (const Fr*)dx.p, (Fr*)dy.p, true, st);
+      rc = ntt_import(t, (const Fr*)dx.p, (F29*)dz.p, false, st);
+      if (!rc) rc = ntt_dif_inverse(t, vz, 1, st);
+      if (!rc) rc = ntt_export(t, (const F29*)dz.p, (Fr*)dy.p, true, true, st);
     } else {
-      rc = ntt_scale_bitrev(t, (const Fr*)dx.p, (Fr*)dy.p, false, st);
-      if (!rc) rc = ntt_dit_forward(t, vy, 1, st);
+      rc = ntt_import(t, (const Fr*)dx.p, (F29*)dz.p, true, st);
+      if (!rc) rc = ntt_dit_forward(t, vz, 1, st);
+      if (!rc) rc = ntt_export(t, (const F29*)dz.p, (Fr*)dy.p, false, false, st);
     }
   }
   if (!rc && hipMemcpyAsync(buf, dy.p, n * 32, hipMemcpyDeviceToHost, st) != hipSuccess) { set_error("hipMemcpy failed"); rc = G16_E_HIP; }

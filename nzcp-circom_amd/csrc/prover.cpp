@@ -125,7 +125,8 @@ struct g16_prover {
   MsmWorkspace* ws[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};  // one per MSM: all five run concurrently
   hipStream_t mst[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};  // A, B1, B2, C on their own streams; H on `st`
   hipEvent_t mev[5][2] = {};
-  Fr *d_a = nullptr, *d_b = nullptr, *d_c = nullptr, *d_p = nullptr;
+  F29 *d_a = nullptr, *d_b = nullptr, *d_c = nullptr;   // QAP/NTT vectors, lazy 9x29 format
+  Fr* d_p = nullptr;                                    // H-MSM scalars, standard form
   std::vector<Fr*> slot_dev;
   std::vector<std::vector<uint8_t>> slot_pub;
   std::vector<uint8_t> winbuf;
@@ -136,8 +137,8 @@ struct g16_prover {
   ~g16_prover() {
     (void)hipSetDevice(device);
     for (Fr* p : slot_dev) if (p) (void)hipFree(p);
-    Fr* vs[] = {d_a, d_b, d_c, d_p};
-    for (Fr* p : vs) if (p) (void)hipFree(p);
+    void* vs[] = {d_a, d_b, d_c, d_p};
+    for (void* p : vs) if (p) (void)hipFree(p);
     for (int m = 0; m < 2; m++) {
       if (csr.row_ptr[m]) (void)hipFree(csr.row_ptr[m]);
       if (csr.col[m]) (void)hipFree(csr.col[m]);
@@ -207,11 +208,17 @@ static int build_csr(g16_prover* P, const Section& s4) {
     P->csr.nnz[m] = nnz;
     G16_HIP(hipMalloc(&P->csr.row_ptr[m], ((size_t)N + 1) * 4));
     G16_HIP(hipMalloc(&P->csr.col[m], (nnz + 1) * 4));
-    G16_HIP(hipMalloc(&P->csr.val[m], (nnz + 1) * sizeof(Fr)));
+    G16_HIP(hipMalloc(&P->csr.val[m], (nnz + 1) * sizeof(F29)));
     G16_HIP(hipMemcpy(P->csr.row_ptr[m], rp[m].data(), ((size_t)N + 1) * 4, hipMemcpyHostToDevice));
     if (nnz) {
       G16_HIP(hipMemcpy(P->csr.col[m], col[m].data(), nnz * 4, hipMemcpyHostToDevice));
-      G16_HIP(hipMemcpy(P->csr.val[m], val[m].data(), nnz * sizeof(Fr), hipMemcpyHostToDevice));
+      Fr* tmp = nullptr;   // file words -> lazy coefficient format, once
+      G16_HIP(hipMalloc(&tmp, nnz * sizeof(Fr)));
+      G16_HIP(hipMemcpy(tmp, val[m].data(), nnz * sizeof(Fr), hipMemcpyHostToDevice));
+      int rc = qap_convert_coefs(tmp, P->csr.val[m], nnz, P->st);
+      if (!rc && hipStreamSynchronize(P->st) != hipSuccess) { set_error("coefficient conversion failed"); rc = G16_E_HIP; }
+      (void)hipFree(tmp);
+      if (rc) return rc;
     }
   }
   return G16_OK;
@@ -305,11 +312,11 @@ static int create_impl(const uint8_t* zkey, size_t len, const g16_opts* opts, g1
     G16_HIP(hipEventCreate(&P->mev[i][0]));
     G16_HIP(hipEventCreate(&P->mev[i][1]));
   }
-  const size_t vb = (size_t)P->N * sizeof(Fr);
+  const size_t vb = (size_t)P->N * sizeof(F29);
   G16_HIP(hipMalloc(&P->d_a, vb));
   G16_HIP(hipMalloc(&P->d_b, vb));
   G16_HIP(hipMalloc(&P->d_c, vb));
-  G16_HIP(hipMalloc(&P->d_p, vb));
+  G16_HIP(hipMalloc(&P->d_p, (size_t)P->N * sizeof(Fr)));
   size_t wb = 0;
   for (auto& m : P->msm) {
     const size_t b = (size_t)(m.W + 1) * msm_point_bytes(m.curve);
@@ -385,7 +392,7 @@ static int device_impl(g16_prover* P, uint32_t slot, Partial& out) {
   // critical chain first (host launch order matters: ~60 witness-MSM launches cost ~0.3 ms of host time)
   if ((rc = qap_eval(P->csr, d_w, P->d_a, P->d_b, P->d_c, P->st))) return rc;
   G16_HIP(hipEventRecord(P->ev[3], P->st));
-  Fr* vecs[3] = {P->d_a, P->d_b, P->d_c};
+  F29* vecs[3] = {P->d_a, P->d_b, P->d_c};
   if ((rc = ntt_dif_inverse(P->ntt, vecs, 3, P->st))) return rc;
   if ((rc = ntt_coset_scale(P->ntt, vecs, 3, P->st))) return rc;
   if ((rc = ntt_dit_forward(P->ntt, vecs, 3, P->st))) return rc;

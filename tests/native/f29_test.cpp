@@ -7,6 +7,7 @@
 #include <string.h>
 
 #include "ec29.cuh"
+#include "fr29.cuh"
 
 using namespace g16;
 
@@ -114,6 +115,44 @@ int main() {
       }
     CHECK(f29_is_zero(f29_from_fq(z)) && f29_is_literal_zero(f29_zero()));
     CHECK(fp_eq(f29_to_fq(f29_one()), one));
+  }
+  // ---- Fr in the same format: conversions, weak reduction, NTT-style lazy chains
+  for (int it = 0; it < 100000; it++) {
+    Fr a, b;
+    for (int i = 0; i < 8; i++) { a.v[i] = (uint32_t)rnd(); b.v[i] = (uint32_t)rnd(); }
+    a.v[7] &= 0x1fffffffu; b.v[7] &= 0x1fffffffu;       // canonical residues (< 2^253 < r)
+    const F29 A = fr29_from_fr(a), B = fr29_from_fr(b);
+    CHECK(fp_eq(fr29_to_fr(A), a));
+    CHECK(fp_eq(fr29_to_fr(fr29_mul(A, B)), fp_mul(a, b)));
+    CHECK(fp_eq(fr29_to_fr(fr29_sub<2>(A, B)), fp_sub(a, b)));
+    // plain <-> Mont261: from_plain(x) represents x, to_plain inverts it
+    CHECK(fp_eq(fr29_to_plain(fr29_from_plain(a)), a));
+    CHECK(fp_eq(fr29_to_fr(fr29_from_plain(a)), fp_to_mont(a)));
+    // zkey coefficient path: file word = coef*R256^2 (plain); product with plain witness word
+    const Fr coefm = fp_to_mont(a);                 // Montgomery(coef)
+    const Fr file = fp_to_mont(coefm);              // coef * R256^2 as stored by snarkjs
+    const F29 t = fr29_mul(fr29_from_zkey_coef(file), fr29_repack(b));
+    CHECK(fp_eq(fr29_to_fr(t), fp_mul(coefm, fp_to_mont(b))));   // Mont(coef * w)
+    // DIF-like growth then weak reduction: ((A+B)+(A+B))+... up to < 16r
+    F29 s = fr29_add(A, B);
+    Fr sc = fp_add(a, b);
+    for (int k = 0; k < 2; k++) { s = fr29_add(s, s); sc = fp_dbl(sc); }   // < 8r
+    F29 d = fr29_sub<8>(A, s);                                            // A + 8r - s < 9.1r
+    Fr dc = fp_sub(a, sc);
+    const F29 wr = fr29_weak_reduce(d);
+    CHECK(wr.l[8] <= Fr29C::P[8] + 1);                                    // < ~1.0001 r
+    CHECK(fp_eq(fr29_to_fr(wr), dc));
+    CHECK(fp_eq(fr29_to_fr(fr29_mul(d, s)), fp_mul(dc, sc)));
+    CHECK(fp_eq(fr29_to_fr(fr29_weak_reduce(s)), sc));
+  }
+  {
+    Fr z = fp_zero<FrParams>();
+    CHECK(fp_eq(fr29_to_plain(fr29_weak_reduce(fr29_from_plain(z))), z));
+    Fr one = fp_zero<FrParams>(); one.v[0] = 1;
+    CHECK(fp_eq(fr29_to_plain(fr29_pow_u64(fr29_from_plain(one), 12345)), one));
+    Fr three = fp_zero<FrParams>(); three.v[0] = 3;
+    Fr e243 = fp_zero<FrParams>(); e243.v[0] = 243;
+    CHECK(fp_eq(fr29_to_plain(fr29_pow_u64(fr29_from_plain(three), 5)), e243));
   }
   printf("field: ok\n");
   // ---- curves
