@@ -1,0 +1,90 @@
+"""GPU parity on the edge cases of the path: smallest domains, no public signals, degenerate
+witnesses (all zero / all one / all r-1: empty MSMs, one giant 'ones' bucket, carry-heavy digits),
+proving keys whose B sections are entirely infinity, and every auto-chosen window size."""
+import random
+
+import pytest
+
+import bn254 as b
+import formats as f
+import groth16 as g
+import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _prove_both(amd, zkb, w, r, s, **kw):
+    zk = f.read_zkey(zkb)
+    prover = amd.Prover(zkb, **kw)
+    proof, pub = prover.prove(f.write_wtns(w), f.le(r), f.le(s))
+    prover.close()
+    (A, B, C), opub = g.prove(zk, w, r, s)
+    assert proof == f.proof_obj(A, B, C)
+    assert pub == [str(x) for x in opub]
+    return zk, (A, B, C), opub
+
+
+@pytest.mark.parametrize("n,p,m", [(2, 0, 1), (3, 1, 1), (5, 0, 2), (9, 3, 4)])
+def test_smallest_circuits(amd, n, p, m):
+    """domain sizes 2..8, including nPublic = 0 (empty public.json)."""
+    rows, w = synth.make(n, p, m, 300 + n)
+    assert synth.check_r1cs(rows, w)
+    zk, _ = g.setup(n, p, rows, g.trapdoor(301 + n))
+    _, proof, pub = _prove_both(amd, f.write_zkey(zk), w, 12345, 67890)
+    assert g.verify(zk, pub, proof)
+    assert len(pub) == p
+
+
+@pytest.mark.parametrize("kind", ["zeros", "ones", "minus_one", "r_half"])
+def test_degenerate_witnesses(amd, kind):
+    """Not satisfying assignments -- parity of the arithmetic only: empty digit lists, every scalar in
+    the ones pseudo-window, all-ones bit patterns (every signed digit negative with carries)."""
+    n, p, m = 200, 4, 150
+    zkb, _, _ = amd.synth_setup(n, p, m, 77)
+    val = {"zeros": 0, "ones": 1, "minus_one": b.R - 1, "r_half": (b.R - 1) // 2}[kind]
+    w = [1] + [val] * (n - 1)
+    _prove_both(amd, zkb, w, 3, 5)
+
+
+def test_blinding_edge_values(amd):
+    zkb, wt, _ = amd.synth_setup(64, 2, 40, 5)
+    w = f.read_wtns(wt)["w"]
+    for r, s in ((0, 0), (1, b.R - 1), (b.R - 1, b.R - 1)):
+        _prove_both(amd, zkb, w, r, s)
+
+
+def test_all_infinity_b_sections(amd):
+    """A circuit whose B polynomials vanish on every signal: B1/B2 MSMs run over zero bases."""
+    n, p, m = 40, 2, 20
+    rows, w = synth.make(n, p, m, 9)
+    rows = [(A, [], C) for (A, _, C) in rows]          # B = 0 everywhere (witness need not satisfy)
+    zk, _ = g.setup(n, p, rows, g.trapdoor(10))
+    assert all(P is None for P in zk["B1"]) and all(P is None for P in zk["B2"])
+    _prove_both(amd, f.write_zkey(zk), w, 11, 13)
+
+
+@pytest.mark.parametrize("c", [2, 3, 4, 7, 9, 10, 12, 14, 15, 16])
+def test_every_window_size(amd, c):
+    """window_bits override: narrow top windows (heavy-bucket path) and the widest ones."""
+    zkb, wt, _ = amd.synth_setup(500, 5, 400, 21)
+    w = f.read_wtns(wt)["w"]
+    _prove_both(amd, zkb, w, 7, 9, window_bits=c)
+
+
+def test_task_len_extremes(amd):
+    zkb, wt, _ = amd.synth_setup(700, 513, 100, 22)
+    w = f.read_wtns(wt)["w"]
+    for tl in (1, 2, 1000):
+        _prove_both(amd, zkb, w, 7, 9, task_len=tl)
+
+
+def test_fft_sizes_one_and_two(amd):
+    rng = random.Random(1)
+    for n in (1, 2):
+        vals = [rng.randrange(b.R) for _ in range(n)]
+        mont = b"".join(f.le(v * b.RR % b.R) for v in vals)
+        rinv = pow(b.RR, -1, b.R)
+        out = amd.fr_fft(mont)
+        assert [int.from_bytes(out[i * 32:(i + 1) * 32], "little") * rinv % b.R for i in range(n)] == g.ntt(vals)
+        back = amd.fr_fft(out, inverse=True)
+        assert back == mont
