@@ -29,10 +29,9 @@
 namespace g16 {
 
 struct MsmWorkspace {
-  uint32_t max_entries = 0, max_buckets = 0, max_tasks = 0, max_seg = 0;
+  uint32_t max_entries = 0, max_buckets = 0, max_tasks = 0;
   uint32_t* d_cnt = nullptr;
   uint32_t* d_off = nullptr;
-  uint32_t* d_cursor = nullptr;
   uint32_t* d_toff = nullptr;
   uint32_t* d_sorted = nullptr;
   uint2* d_task_desc = nullptr;
@@ -170,7 +169,7 @@ static __global__ __launch_bounds__(256) void msm_hist_start_kernel(uint32_t* __
   }
 }
 
-// Exclusive scans off = scan(cnt), toff = scan(ceil(cnt/task_len)), cursor = off, in three launches:
+// Exclusive scans off = scan(cnt), toff = scan(ceil(cnt/task_len)) in three launches:
 // per-tile sums (2048 counters per workgroup) -> one workgroup scans the tile sums -> per-tile
 // local scan + tile offset.
 static constexpr uint32_t kScanTile = 2048;   // 256 threads x 8 counters
@@ -230,7 +229,6 @@ static __global__ __launch_bounds__(256) void msm_scan_apply_kernel(const uint32
                                                              const uint32_t* __restrict__ tile_a,
                                                              const uint32_t* __restrict__ tile_b,
                                                              uint32_t* __restrict__ off,
-                                                             uint32_t* __restrict__ cursor,
                                                              uint32_t* __restrict__ toff) {
   __shared__ uint32_t sh_a[256], sh_b[256];
   const uint32_t tid = threadIdx.x, base = blockIdx.x * kScanTile + tid * 8;
@@ -255,7 +253,6 @@ static __global__ __launch_bounds__(256) void msm_scan_apply_kernel(const uint32
   for (int k = 0; k < 8; k++) {
     if (base + k < nb) {
       off[base + k] = pa;
-      cursor[base + k] = pa;
       toff[base + k] = pb;
     }
     pa += v[k];
@@ -533,7 +530,7 @@ int msm_launch_t(const MsmInstance& m, MsmWorkspace* ws, const Fr* d_scalars, hi
   msm_scan_tiles_kernel<<<ntiles, 256, 0, st>>>(ws->d_cnt, nb, m.task_len, ws->d_tile_a, ws->d_tile_b);
   msm_scan_top_kernel<<<1, 1024, 0, st>>>(ws->d_tile_a, ws->d_tile_b, ntiles, ws->d_off + nb, ws->d_toff + nb);
   msm_scan_apply_kernel<<<ntiles, 256, 0, st>>>(ws->d_cnt, nb, m.task_len, ws->d_tile_a, ws->d_tile_b, ws->d_off,
-                                                ws->d_cursor, ws->d_toff);
+                                                ws->d_toff);
   msm_hist_start_kernel<<<(nb + 255) / 256, 256, 0, st>>>(ws->d_hist, nb, B, chunks, ws->d_off);
   msm_sort_kernel<1><<<WT * chunks, 1024, lds_bytes, st>>>(ws->d_dig, m.n, B, chunks, per, ws->d_hist, ws->d_sorted);
   msm_task_fill_kernel<<<(nb + 255) / 256, 256, 0, st>>>(ws->d_off, ws->d_toff, nb, m.task_len, ws->d_task_desc);

@@ -134,7 +134,6 @@ int msm_workspace_create(MsmWorkspace** out, const MsmInstance* insts, int ninst
   G16_HIP(hipMalloc(&ws->d_hist, (hist_words + 4) * 4));
   G16_HIP(hipMalloc(&ws->d_cnt, ((size_t)ws->max_buckets + 1) * 4));
   G16_HIP(hipMalloc(&ws->d_off, ((size_t)ws->max_buckets + 1) * 4));
-  G16_HIP(hipMalloc(&ws->d_cursor, ((size_t)ws->max_buckets + 1) * 4));
   G16_HIP(hipMalloc(&ws->d_toff, ((size_t)ws->max_buckets + 1) * 4));
   G16_HIP(hipMalloc(&ws->d_sorted, ((size_t)ws->max_entries + 1) * 4));
   G16_HIP(hipMalloc(&ws->d_task_desc, ((size_t)ws->max_tasks + 1) * sizeof(uint2)));
@@ -156,7 +155,7 @@ int msm_workspace_create(MsmWorkspace** out, const MsmInstance* insts, int ninst
 
 void msm_workspace_destroy(MsmWorkspace* ws) {
   if (!ws) return;
-  void* ptrs[] = {ws->d_cnt, ws->d_off, ws->d_cursor, ws->d_toff, ws->d_sorted, ws->d_task_desc, ws->d_queue, ws->d_tile_a, ws->d_tile_b,
+  void* ptrs[] = {ws->d_cnt, ws->d_off, ws->d_toff, ws->d_sorted, ws->d_task_desc, ws->d_queue, ws->d_tile_a, ws->d_tile_b,
                   ws->d_partial, ws->d_seg, ws->d_red, ws->d_bsum, ws->d_heavy, ws->d_dig, ws->d_hist, ws->d_canon};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);

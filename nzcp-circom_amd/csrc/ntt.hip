@@ -8,12 +8,12 @@
 //   qap_joinABC + frm_batchFromMontgomery -> ntt_join_abc
 // DIF-then-DIT removes both bit-reversal permutations the reference performs.
 //
-// HBM layout: a vector is N contiguous 32-byte Montgomery residues.  One launch covers up to
-// 10 butterfly stages: a workgroup stages a 1024-element tile (32 KiB) in LDS, runs the stages
+// HBM layout: a vector is N contiguous 40-byte elements (9 x 29-bit limbs + pad).  One launch covers up
+// to 10 butterfly stages: a workgroup stages a 1024-element tile (40 KiB) in LDS, runs the stages
 // with __syncthreads between them and writes the tile back, so a 2^21 transform is 3 passes
 // over HBM instead of 21.  Tiles of later passes are 2^S rows x T columns with T >= 4
-// contiguous elements (128 B runs) for coalescing.  Index math validated by the Python model in
-// tests/test_ntt_plan.py.
+// contiguous elements (160 B runs) for coalescing.  Index math validated by the Python model in
+// tests/test_cpu_ntt_plan.py.
 //
 // Arithmetic: Fr in the 9 x 29-bit lazy format (fr29.cuh; 40-byte elements in HBM and LDS).  A
 // butterfly is one 162-mad product + a limb-wise add and sub; values drift upwards between

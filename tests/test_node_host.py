@@ -80,3 +80,37 @@ def test_resident_prover_and_random_blinding(addon):
     assert out["a"]["proof"] == meta["proof"] and out["a"]["publicSignals"] == meta["public"]
     assert out["b"]["proof"] != out["c"]["proof"] and out["b"]["publicSignals"] == meta["public"]
     assert out["bad"] == "Invalid witness length. Circuit: 150, witness: 24"
+
+
+@needs_node
+def test_nzcp_input_builder_example_pass():
+    """pass URI -> ToBeSigned / circuit input / expected public signals, pinned by the
+    reference's golden data for the MoH example pass (URI = the test input at
+    /root/reference/test/nzcp.js:51, kept as a fixture in tests/golden/example_pass_uri.txt)."""
+    uri = open(golden_path("example_pass_uri.txt")).read().strip()
+    script = f"""
+    const n = require({json.dumps(os.path.join(JS, 'nzcpInput.js'))});
+    const uri = {json.dumps(uri)};
+    const tbs = n.toBeSigned(uri);
+    const inp = n.circuitInput(uri, 314);
+    const pub = n.expectedPublicSignals(uri);
+    let tooLong = "";
+    try {{ n.circuitInput(uri, 300); }} catch (e) {{ tooLong = e.message; }}
+    console.log(JSON.stringify({{hex: tbs.toString("hex"), len: inp.toBeSignedLen, nbits: inp.toBeSigned.length,
+                                first16: inp.toBeSigned.slice(0, 16), claims: n.claims(uri), npub: pub.length,
+                                h1: pub.slice(0, 256).join(""), h2: pub.slice(256, 512).join(""), exp: pub[512],
+                                match: n.publicSignalsMatchPass(pub, uri), tooLong}}));
+    """
+    r = run_node(script)
+    assert r.returncode == 0, r.stderr
+    o = json.loads(r.stdout)
+    assert o["len"] == 314 and o["nbits"] == 314 * 8
+    assert o["hex"].startswith("846a5369676e6174757265314aa204456b65792d3101264059011fa501781e6469643a7765623a6e7a6370")
+    import hashlib
+    assert hashlib.sha256(bytes.fromhex(o["hex"])).hexdigest() == "271ce33d671a2d3b816d788135f4343e14bc66802f8cd841faac939e8c11f3ee"
+    assert o["first16"] == [1, 0, 0, 0, 0, 1, 0, 0, 0, 1, 1, 0, 1, 0, 1, 0]          # 0x84 0x6a, MSB first
+    assert (o["claims"]["givenName"], o["claims"]["familyName"], o["claims"]["dob"]) == ("Jack", "Sparrow", "1960-04-16")
+    assert o["npub"] == 513 and o["exp"] == "1951416330" and o["match"] is True
+    assert "%064x" % int(o["h1"], 2) == "5fb355822221720ea4ce6734e5a09e459d452574a19310c0cea7c141f43a3dab"
+    assert "%064x" % int(o["h2"], 2) == "271ce33d671a2d3b816d788135f4343e14bc66802f8cd841faac939e8c11f3ee"
+    assert "circuit maximum is 300" in o["tooLong"]
