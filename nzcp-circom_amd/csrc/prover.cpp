@@ -115,30 +115,46 @@ using namespace g16;
 struct g16_prover {
   int device = 0;
   int shard_rank = 0, shard_count = 1;
-  hipStream_t st = nullptr;
+  hipStream_t st = nullptr;     // = ctx[0].st: create-time work and witness staging
   uint32_t nVars = 0, nPublic = 0, N = 0, nCoefs = 0;
   int L = 0;
   KeyPoints kp;
   QapCsr csr;
   NttTables ntt;
-  MsmInstance msm[5];  // A, B1, B2, C, H
-  MsmWorkspace* ws[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};  // one per MSM: all five run concurrently
-  hipStream_t mst[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};  // A, B1, B2, C on their own streams; H on `st`
-  hipEvent_t mev[5][2] = {};
-  F29 *d_a = nullptr, *d_b = nullptr, *d_c = nullptr;   // QAP/NTT vectors, lazy 9x29 format
-  Fr* d_p = nullptr;                                    // H-MSM scalars, standard form
+  MsmInstance msm[5];  // A, B1, B2, C, H: resident bases, shared by every context
+  // Per-proof scratch.  Two contexts so that g16_prove_batch can have proof i+1 on the GPU while the
+  // host collects and finishes proof i (BASELINE config 3); single proofs use ctx[0].
+  struct ProofCtx {
+    hipStream_t st = nullptr;                                         // QAP -> NTT -> H-MSM (critical chain)
+    hipStream_t mst[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};  // A, B1, B2, C on their own streams; [4] = st
+    MsmWorkspace* ws[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};  // one per MSM: all five run concurrently
+    hipEvent_t ev[8] = {};
+    hipEvent_t mev[5][2] = {};
+    F29 *d_a = nullptr, *d_b = nullptr, *d_c = nullptr;   // QAP/NTT vectors, lazy 9x29 format
+    Fr* d_p = nullptr;                                    // H-MSM scalars, standard form
+    Fr* d_w = nullptr;                                    // batch mode: this context's witness copy
+    std::vector<uint8_t> winbuf;
+    g16_timings tm{};
+  };
+  static constexpr int kCtx = 2;
+  ProofCtx ctx[kCtx];
   std::vector<Fr*> slot_dev;
   std::vector<std::vector<uint8_t>> slot_pub;
-  std::vector<uint8_t> winbuf;
-  g16_timings tm{};
-  hipEvent_t ev[8] = {};
+  g16_timings tm{};    // of the last completed proof
   std::mutex mu;
 
   ~g16_prover() {
     (void)hipSetDevice(device);
     for (Fr* p : slot_dev) if (p) (void)hipFree(p);
-    void* vs[] = {d_a, d_b, d_c, d_p};
-    for (void* p : vs) if (p) (void)hipFree(p);
+    for (auto& c : ctx) {
+      void* vs[] = {c.d_a, c.d_b, c.d_c, c.d_p, c.d_w};
+      for (void* p : vs) if (p) (void)hipFree(p);
+      for (auto& w : c.ws) msm_workspace_destroy(w);
+      for (int i = 0; i < 4; i++) if (c.mst[i] && c.mst[i] != c.st) (void)hipStreamDestroy(c.mst[i]);
+      for (auto& e : c.mev) { if (e[0]) (void)hipEventDestroy(e[0]); if (e[1]) (void)hipEventDestroy(e[1]); }
+      for (auto& e : c.ev) if (e) (void)hipEventDestroy(e);
+      if (c.st) (void)hipStreamDestroy(c.st);
+    }
     for (int m = 0; m < 2; m++) {
       if (csr.row_ptr[m]) (void)hipFree(csr.row_ptr[m]);
       if (csr.col[m]) (void)hipFree(csr.col[m]);
@@ -146,11 +162,6 @@ struct g16_prover {
     }
     ntt_tables_destroy(ntt);
     for (auto& m : msm) msm_instance_destroy(m);
-    for (auto& w : ws) msm_workspace_destroy(w);
-    for (int i = 0; i < 4; i++) if (mst[i] && mst[i] != st) (void)hipStreamDestroy(mst[i]);
-    for (auto& e : mev) { if (e[0]) (void)hipEventDestroy(e[0]); if (e[1]) (void)hipEventDestroy(e[1]); }
-    for (auto& e : ev) if (e) (void)hipEventDestroy(e);
-    if (st) (void)hipStreamDestroy(st);
   }
 };
 
@@ -278,8 +289,11 @@ static int create_impl(const uint8_t* zkey, size_t len, const g16_opts* opts, g1
   // main stream (QAP -> NTT -> H-MSM, the critical path) at high priority, witness MSM streams low
   int prio_lo = 0, prio_hi = 0;
   G16_HIP(hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
-  G16_HIP(hipStreamCreateWithPriority(&P->st, hipStreamNonBlocking, prio_hi));
-  for (auto& e : P->ev) G16_HIP(hipEventCreate(&e));
+  for (auto& c : P->ctx) {
+    G16_HIP(hipStreamCreateWithPriority(&c.st, hipStreamNonBlocking, prio_hi));
+    for (auto& e : c.ev) G16_HIP(hipEventCreate(&e));
+  }
+  P->st = P->ctx[0].st;
   if ((rc = build_csr(P, s4))) return rc;
   if ((rc = ntt_tables_create(P->ntt, P->L, P->st))) return rc;
   MsmConfig cfg;
@@ -301,28 +315,30 @@ static int create_impl(const uint8_t* zkey, size_t len, const g16_opts* opts, g1
     if ((rc = msm_instance_create(P->msm[i], curve[i], sb[i].p + (size_t)lo * psz, hi - lo, base_off[i] + lo, cfg)))
       return rc;
   }
-  for (int i = 0; i < 5; i++) {
-    if ((rc = msm_workspace_create(&P->ws[i], &P->msm[i], 1))) return rc;
-    // the G2 chain (B2) is the longest after the H chain: high priority as well
-    // G16_SERIAL_MSM=1 (profiling aid): every MSM on the main stream, so kernel times are standalone
-    const bool serial = getenv("G16_SERIAL_MSM") && atoi(getenv("G16_SERIAL_MSM"));
-    if (i < 4 && serial) P->mst[i] = P->st;
-    else if (i < 4) G16_HIP(hipStreamCreateWithPriority(&P->mst[i], hipStreamNonBlocking, i == 2 ? prio_hi : prio_lo));
-    else P->mst[4] = P->st;
-    G16_HIP(hipEventCreate(&P->mev[i][0]));
-    G16_HIP(hipEventCreate(&P->mev[i][1]));
-  }
-  const size_t vb = (size_t)P->N * sizeof(F29);
-  G16_HIP(hipMalloc(&P->d_a, vb));
-  G16_HIP(hipMalloc(&P->d_b, vb));
-  G16_HIP(hipMalloc(&P->d_c, vb));
-  G16_HIP(hipMalloc(&P->d_p, (size_t)P->N * sizeof(Fr)));
+  // G16_SERIAL_MSM=1 (profiling aid): every MSM on the main stream, so kernel times are standalone
+  const bool serial = getenv("G16_SERIAL_MSM") && atoi(getenv("G16_SERIAL_MSM"));
   size_t wb = 0;
   for (auto& m : P->msm) {
     const size_t b = (size_t)(m.W + 1) * msm_point_bytes(m.curve);
     if (b > wb) wb = b;
   }
-  P->winbuf.resize(wb);
+  for (auto& c : P->ctx) {
+    for (int i = 0; i < 5; i++) {
+      if ((rc = msm_workspace_create(&c.ws[i], &P->msm[i], 1))) return rc;
+      // the G2 chain (B2) is the longest after the H chain: high priority as well
+      if (i < 4 && serial) c.mst[i] = c.st;
+      else if (i < 4) G16_HIP(hipStreamCreateWithPriority(&c.mst[i], hipStreamNonBlocking, i == 2 ? prio_hi : prio_lo));
+      else c.mst[4] = c.st;
+      G16_HIP(hipEventCreate(&c.mev[i][0]));
+      G16_HIP(hipEventCreate(&c.mev[i][1]));
+    }
+    const size_t vb = (size_t)P->N * sizeof(F29);
+    G16_HIP(hipMalloc(&c.d_a, vb));
+    G16_HIP(hipMalloc(&c.d_b, vb));
+    G16_HIP(hipMalloc(&c.d_c, vb));
+    G16_HIP(hipMalloc(&c.d_p, (size_t)P->N * sizeof(Fr)));
+    c.winbuf.resize(wb);
+  }
   G16_HIP(hipStreamSynchronize(P->st));
   return G16_OK;
 }
@@ -360,66 +376,85 @@ static int stage_impl(g16_prover* P, uint32_t slot, const uint8_t* wtns, size_t 
   G16_HIP(hipSetDevice(P->device));
   if (P->slot_dev.size() <= slot) { P->slot_dev.resize(slot + 1, nullptr); P->slot_pub.resize(slot + 1); }
   if (!P->slot_dev[slot]) G16_HIP(hipMalloc(&P->slot_dev[slot], (size_t)P->nVars * sizeof(Fr)));
-  G16_HIP(hipEventRecord(P->ev[0], P->st));
+  auto& c0 = P->ctx[0];
+  G16_HIP(hipEventRecord(c0.ev[0], P->st));
   G16_HIP(hipMemcpyAsync(P->slot_dev[slot], body, (size_t)P->nVars * 32, hipMemcpyHostToDevice, P->st));
-  G16_HIP(hipEventRecord(P->ev[1], P->st));
+  G16_HIP(hipEventRecord(c0.ev[1], P->st));
   G16_HIP(hipStreamSynchronize(P->st));
-  (void)hipEventElapsedTime(&P->tm.upload_ms, P->ev[0], P->ev[1]);
+  (void)hipEventElapsedTime(&c0.tm.upload_ms, c0.ev[0], c0.ev[1]);
+  P->tm.upload_ms = c0.tm.upload_ms;
   P->slot_pub[slot].assign(body + 32, body + 32 + (size_t)P->nPublic * 32);
   return G16_OK;
 }
 
+using ProofCtx = g16_prover::ProofCtx;
+
 template <class F>
-static int collect_one_msm(g16_prover* P, int i, XYZZ<F>& out) {
-  int rc = msm_collect(P->ws[i], P->winbuf.data(), P->mst[i]);
+static int collect_one_msm(g16_prover* P, ProofCtx& c, int i, XYZZ<F>& out) {
+  int rc = msm_collect(c.ws[i], c.winbuf.data(), c.mst[i]);
   if (rc) return rc;
-  (void)hipEventElapsedTime(&P->tm.msm_ms[i], P->mev[i][0], P->mev[i][1]);
-  P->tm.msm_accum_kernel_ms[i] = msm_last_accum_ms(P->ws[i]);
-  msm_combine_windows<F>(out, P->winbuf.data(), P->msm[i].W, P->msm[i].c);
+  (void)hipEventElapsedTime(&c.tm.msm_ms[i], c.mev[i][0], c.mev[i][1]);
+  c.tm.msm_accum_kernel_ms[i] = msm_last_accum_ms(c.ws[i]);
+  msm_combine_windows<F>(out, c.winbuf.data(), P->msm[i].W, P->msm[i].c);
   return G16_OK;
 }
 
-// The device pipeline of one proof on a staged witness.  The four witness MSMs (A, B1, B2, C) do
-// not depend on the H polynomial, so they are enqueued on their own streams first and overlap with
-// QAP -> NTTs -> join -> H-MSM on the main stream; the host folds each MSM's window sums while the
-// later ones are still running.
-static int device_impl(g16_prover* P, uint32_t slot, Partial& out) {
-  if (slot >= P->slot_dev.size() || !P->slot_dev[slot]) { set_error("witness slot not staged"); return G16_E_STATE; }
+// Enqueue the device pipeline of one proof on context `c` (no host synchronisation).  The four
+// witness MSMs (A, B1, B2, C) do not depend on the H polynomial: they run on their own streams and
+// overlap with QAP -> NTTs -> join -> H-MSM on the context's main stream.
+static int launch_ctx(g16_prover* P, ProofCtx& c, const Fr* d_w) {
   G16_HIP(hipSetDevice(P->device));
-  const Fr* d_w = P->slot_dev[slot];
   int rc;
-  G16_HIP(hipEventRecord(P->ev[2], P->st));
+  G16_HIP(hipEventRecord(c.ev[2], c.st));
   // critical chain first (host launch order matters: ~60 witness-MSM launches cost ~0.3 ms of host time)
-  if ((rc = qap_eval(P->csr, d_w, P->d_a, P->d_b, P->d_c, P->st))) return rc;
-  G16_HIP(hipEventRecord(P->ev[3], P->st));
-  F29* vecs[3] = {P->d_a, P->d_b, P->d_c};
-  if ((rc = ntt_dif_inverse(P->ntt, vecs, 3, P->st))) return rc;
-  if ((rc = ntt_coset_scale(P->ntt, vecs, 3, P->st))) return rc;
-  if ((rc = ntt_dit_forward(P->ntt, vecs, 3, P->st))) return rc;
-  if ((rc = ntt_join_abc(P->d_a, P->d_b, P->d_c, P->d_p, P->N, P->st))) return rc;
-  G16_HIP(hipEventRecord(P->ev[4], P->st));
+  if ((rc = qap_eval(P->csr, d_w, c.d_a, c.d_b, c.d_c, c.st))) return rc;
+  G16_HIP(hipEventRecord(c.ev[3], c.st));
+  F29* vecs[3] = {c.d_a, c.d_b, c.d_c};
+  if ((rc = ntt_dif_inverse(P->ntt, vecs, 3, c.st))) return rc;
+  if ((rc = ntt_coset_scale(P->ntt, vecs, 3, c.st))) return rc;
+  if ((rc = ntt_dit_forward(P->ntt, vecs, 3, c.st))) return rc;
+  if ((rc = ntt_join_abc(c.d_a, c.d_b, c.d_c, c.d_p, P->N, c.st))) return rc;
+  G16_HIP(hipEventRecord(c.ev[4], c.st));
   static const int order[4] = {2, 3, 0, 1};   // longest chains first: B2 (G2), C, A, B1
   for (int oi = 0; oi < 4; oi++) {
     const int i = order[oi];
-    if (P->mst[i] != P->st) G16_HIP(hipStreamWaitEvent(P->mst[i], P->ev[2], 0));
-    G16_HIP(hipEventRecord(P->mev[i][0], P->mst[i]));
-    if ((rc = msm_launch(P->msm[i], P->ws[i], d_w, P->mst[i]))) return rc;
-    G16_HIP(hipEventRecord(P->mev[i][1], P->mst[i]));
+    if (c.mst[i] != c.st) G16_HIP(hipStreamWaitEvent(c.mst[i], c.ev[2], 0));
+    G16_HIP(hipEventRecord(c.mev[i][0], c.mst[i]));
+    if ((rc = msm_launch(P->msm[i], c.ws[i], d_w, c.mst[i]))) return rc;
+    G16_HIP(hipEventRecord(c.mev[i][1], c.mst[i]));
   }
-  G16_HIP(hipEventRecord(P->mev[4][0], P->st));
-  if ((rc = msm_launch(P->msm[4], P->ws[4], P->d_p, P->st))) return rc;
-  G16_HIP(hipEventRecord(P->mev[4][1], P->st));
-  if ((rc = collect_one_msm<FqOps>(P, 0, out.A))) return rc;
-  if ((rc = collect_one_msm<FqOps>(P, 1, out.B1))) return rc;
-  if ((rc = collect_one_msm<Fq2Ops>(P, 2, out.B2))) return rc;
-  if ((rc = collect_one_msm<FqOps>(P, 3, out.C))) return rc;
-  if ((rc = collect_one_msm<FqOps>(P, 4, out.H))) return rc;
-  G16_HIP(hipEventRecord(P->ev[5], P->st));
-  G16_HIP(hipEventSynchronize(P->ev[5]));
-  (void)hipEventElapsedTime(&P->tm.qap_ms, P->ev[2], P->ev[3]);
-  (void)hipEventElapsedTime(&P->tm.ntt_ms, P->ev[3], P->ev[4]);
-  (void)hipEventElapsedTime(&P->tm.total_ms, P->ev[2], P->ev[5]);
+  G16_HIP(hipEventRecord(c.mev[4][0], c.st));
+  if ((rc = msm_launch(P->msm[4], c.ws[4], c.d_p, c.st))) return rc;
+  G16_HIP(hipEventRecord(c.mev[4][1], c.st));
   return G16_OK;
+}
+
+// Wait for context `c` and fold each MSM's window sums (the host folds the early ones while the
+// later ones still run).
+static int collect_ctx(g16_prover* P, ProofCtx& c, Partial& out) {
+  int rc;
+  if ((rc = collect_one_msm<FqOps>(P, c, 0, out.A))) return rc;
+  if ((rc = collect_one_msm<FqOps>(P, c, 1, out.B1))) return rc;
+  if ((rc = collect_one_msm<Fq2Ops>(P, c, 2, out.B2))) return rc;
+  if ((rc = collect_one_msm<FqOps>(P, c, 3, out.C))) return rc;
+  if ((rc = collect_one_msm<FqOps>(P, c, 4, out.H))) return rc;
+  G16_HIP(hipEventRecord(c.ev[5], c.st));
+  G16_HIP(hipEventSynchronize(c.ev[5]));
+  (void)hipEventElapsedTime(&c.tm.qap_ms, c.ev[2], c.ev[3]);
+  (void)hipEventElapsedTime(&c.tm.ntt_ms, c.ev[3], c.ev[4]);
+  (void)hipEventElapsedTime(&c.tm.total_ms, c.ev[2], c.ev[5]);
+  const float up = P->tm.upload_ms;
+  P->tm = c.tm;
+  P->tm.upload_ms = up;
+  return G16_OK;
+}
+
+// One proof on a staged witness (context 0).
+static int device_impl(g16_prover* P, uint32_t slot, Partial& out) {
+  if (slot >= P->slot_dev.size() || !P->slot_dev[slot]) { set_error("witness slot not staged"); return G16_E_STATE; }
+  int rc = launch_ctx(P, P->ctx[0], P->slot_dev[slot]);
+  if (rc) return rc;
+  return collect_ctx(P, P->ctx[0], out);
 }
 
 // Proof assembly on the host: O(1) work, ~1.5k field products.
@@ -547,9 +582,35 @@ int g16_prove(g16_prover* p, const uint8_t* wtns, size_t wtns_len, const uint8_t
 int g16_prove_batch(g16_prover* p, const uint8_t* const* wtns, const size_t* wtns_lens, size_t count,
                     const uint8_t* rs, g16_proof* out, uint8_t* pub) {
   if (!p || !wtns || !wtns_lens || !out) { set_error("NULL argument"); return G16_E_ARG; }
+  std::lock_guard<std::mutex> lk(p->mu);
+  if (p->shard_count != 1) { set_error("sharded handle: use g16_prove_partial/g16_prove_finish"); return G16_E_STATE; }
+  // Software pipeline over the two contexts: while the host waits for, folds and finishes proof i-1,
+  // proof i is already running on the GPU.
+  const size_t wbytes = (size_t)p->nVars * sizeof(Fr);
+  auto finish_one = [&](size_t i) -> int {
+    ProofCtx& c = p->ctx[i % g16_prover::kCtx];
+    Partial part;
+    int rc = collect_ctx(p, c, part);
+    if (rc) return rc;
+    return finish_impl(&p->kp, &part, 1, rs ? rs + i * 64 : nullptr, rs ? rs + i * 64 + 32 : nullptr, &out[i]);
+  };
   for (size_t i = 0; i < count; i++) {
-    int rc = g16_prove(p, wtns[i], wtns_lens[i], rs ? rs + i * 64 : nullptr, rs ? rs + i * 64 + 32 : nullptr,
-                       &out[i], pub ? pub + i * (size_t)p->nPublic * 32 : nullptr);
+    ProofCtx& c = p->ctx[i % g16_prover::kCtx];
+    if (i >= (size_t)g16_prover::kCtx) {   // the context is still busy with proof i - kCtx
+      int rc = finish_one(i - g16_prover::kCtx);
+      if (rc) return rc;
+    }
+    const uint8_t* body = nullptr;
+    int rc = parse_wtns(p, wtns[i], wtns_lens[i], &body);
+    if (rc) return rc;
+    G16_HIP(hipSetDevice(p->device));
+    if (!c.d_w) G16_HIP(hipMalloc(&c.d_w, wbytes));
+    G16_HIP(hipMemcpyAsync(c.d_w, body, wbytes, hipMemcpyHostToDevice, c.st));
+    if (pub && p->nPublic) memcpy(pub + i * (size_t)p->nPublic * 32, body + 32, (size_t)p->nPublic * 32);
+    if ((rc = launch_ctx(p, c, c.d_w))) return rc;
+  }
+  for (size_t i = count > (size_t)g16_prover::kCtx ? count - g16_prover::kCtx : 0; i < count; i++) {
+    int rc = finish_one(i);
     if (rc) return rc;
   }
   return G16_OK;
