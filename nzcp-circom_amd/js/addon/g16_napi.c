@@ -8,6 +8,7 @@
  *
  * Exports:  create(zkey: Buffer, opts: {device, shardRank, shardCount, windowBits, taskLen}) -> Promise<handle>
  *           prove(handle, wtns: Buffer, r: Buffer|null, s: Buffer|null) -> Promise<{proof: Buffer(256), pub: Buffer}>
+ *           proveBatch(handle, wtns: Buffer[], rs: Buffer|null) -> Promise<[{proof, pub}]>
  *           info(handle) -> {nVars, nPublic, domainSize, nCoefs}
  *           timings(handle) -> {...ms}
  *           destroy(handle)
@@ -46,14 +47,19 @@ typedef struct {
   /* prove */
   handle_t* h; const uint8_t* wtns; size_t wtns_len; int have_r, have_s; uint8_t r[32], s[32];
   g16_proof proof; uint8_t* pub; size_t pub_len;
+  /* batch */
+  size_t bcount; const uint8_t** bw; size_t* blen; uint8_t* brs; g16_proof* bproofs; uint8_t* bpub; size_t bpub_each;
+  napi_ref* brefs;
   int rc; char err[512];
-  int is_create;
+  int is_create;   /* 1 = create, 0 = prove, 2 = prove batch */
 } job_t;
 
 static void job_execute(napi_env env, void* data) {
   job_t* j = (job_t*)data;
-  if (j->is_create) {
+  if (j->is_create == 1) {
     j->rc = g16_create(j->zkey, j->zkey_len, &j->opts, &j->created);
+  } else if (j->is_create == 2) {
+    j->rc = g16_prove_batch(j->h->p, j->bw, j->blen, j->bcount, j->brs, j->bproofs, j->bpub);
   } else {
     j->rc = g16_prove(j->h->p, j->wtns, j->wtns_len, j->have_r ? j->r : NULL, j->have_s ? j->s : NULL,
                       &j->proof, j->pub);
@@ -72,7 +78,20 @@ static void job_complete(napi_env env, napi_status status, void* data) {
     napi_create_string_utf8(env, j->rc ? j->err : "g16 addon: async work cancelled", NAPI_AUTO_LENGTH, &msg);
     napi_create_error(env, NULL, msg, &err);
     napi_reject_deferred(env, j->deferred, err);
-  } else if (j->is_create) {
+  } else if (j->is_create == 2) {
+    napi_create_array_with_length(env, j->bcount, &result);
+    for (size_t i = 0; i < j->bcount; i++) {
+      napi_value item, proof, pub;
+      void* dst;
+      napi_create_object(env, &item);
+      napi_create_buffer_copy(env, sizeof(g16_proof), &j->bproofs[i], &dst, &proof);
+      napi_create_buffer_copy(env, j->bpub_each, j->bpub + i * j->bpub_each, &dst, &pub);
+      napi_set_named_property(env, item, "proof", proof);
+      napi_set_named_property(env, item, "pub", pub);
+      napi_set_element(env, result, (uint32_t)i, item);
+    }
+    napi_resolve_deferred(env, j->deferred, result);
+  } else if (j->is_create == 1) {
     handle_t* h = (handle_t*)calloc(1, sizeof(handle_t));
     h->p = j->created;
     napi_create_external(env, h, handle_finalize, NULL, &result);
@@ -88,8 +107,9 @@ static void job_complete(napi_env env, napi_status status, void* data) {
     napi_resolve_deferred(env, j->deferred, result);
   }
   for (int i = 0; i < j->nrefs; i++) napi_delete_reference(env, j->refs[i]);
+  if (j->brefs) { for (size_t i = 0; i < j->bcount; i++) napi_delete_reference(env, j->brefs[i]); free(j->brefs); }
   napi_delete_async_work(env, j->work);
-  free(j->pub);
+  free(j->pub); free(j->bw); free(j->blen); free(j->brs); free(j->bproofs); free(j->bpub);
   free(j);
 }
 
@@ -176,6 +196,54 @@ static napi_value js_prove(napi_env env, napi_callback_info info) {
   return queue_job(env, j, "g16_prove");
 }
 
+/* proveBatch(handle, wtns: Buffer[], rs: Buffer(count*64)|null) -> Promise<[{proof, pub}]>  (g16_prove_batch:
+ * the library pipelines the proofs over two scratch contexts) */
+static napi_value js_prove_batch(napi_env env, napi_callback_info info) {
+  size_t argc = 3;
+  napi_value argv[3];
+  NAPI_OK(napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
+  handle_t* h = NULL;
+  bool isarr = false, isbuf = false;
+  uint32_t n = 0;
+  if (argc < 2 || napi_get_value_external(env, argv[0], (void**)&h) != napi_ok || !h || !h->p ||
+      napi_is_array(env, argv[1], &isarr) != napi_ok || !isarr || napi_get_array_length(env, argv[1], &n) != napi_ok || n == 0) {
+    napi_throw_type_error(env, NULL, "proveBatch(handle, wtns: Buffer[], rs)");
+    return NULL;
+  }
+  job_t* j = (job_t*)calloc(1, sizeof(job_t));
+  j->is_create = 2;
+  j->h = h;
+  j->bcount = n;
+  j->bw = (const uint8_t**)calloc(n, sizeof(uint8_t*));
+  j->blen = (size_t*)calloc(n, sizeof(size_t));
+  j->brefs = (napi_ref*)calloc(n, sizeof(napi_ref));
+  j->bproofs = (g16_proof*)calloc(n, sizeof(g16_proof));
+  g16_info inf;
+  g16_get_info(h->p, &inf);
+  j->bpub_each = (size_t)inf.n_public * 32;
+  j->bpub = (uint8_t*)malloc(j->bpub_each * n + 1);
+  for (uint32_t i = 0; i < n; i++) {
+    napi_value el;
+    void* data;
+    if (napi_get_element(env, argv[1], i, &el) != napi_ok || napi_is_buffer(env, el, &isbuf) != napi_ok || !isbuf ||
+        napi_get_buffer_info(env, el, &data, &j->blen[i]) != napi_ok || napi_create_reference(env, el, 1, &j->brefs[i]) != napi_ok) {
+      napi_throw_type_error(env, NULL, "proveBatch: every witness must be a Buffer");
+      return NULL;   /* small leak on a caller bug; the job never ran */
+    }
+    j->bw[i] = (const uint8_t*)data;
+  }
+  NAPI_OK(napi_create_reference(env, argv[0], 1, &j->refs[j->nrefs++]));
+  if (argc > 2 && napi_is_buffer(env, argv[2], &isbuf) == napi_ok && isbuf) {
+    void* data;
+    size_t len;
+    NAPI_OK(napi_get_buffer_info(env, argv[2], &data, &len));
+    if (len != (size_t)n * 64) { napi_throw_range_error(env, NULL, "rs must hold count*64 bytes"); return NULL; }
+    j->brs = (uint8_t*)malloc(len);
+    memcpy(j->brs, data, len);
+  }
+  return queue_job(env, j, "g16_prove_batch");
+}
+
 static napi_value js_info(napi_env env, napi_callback_info info) {
   size_t argc = 1;
   napi_value argv[1], out, v;
@@ -234,6 +302,7 @@ static napi_value init(napi_env env, napi_value exports) {
   napi_property_descriptor props[] = {
       {"create", NULL, js_create, NULL, NULL, NULL, napi_default, NULL},
       {"prove", NULL, js_prove, NULL, NULL, NULL, napi_default, NULL},
+      {"proveBatch", NULL, js_prove_batch, NULL, NULL, NULL, napi_default, NULL},
       {"info", NULL, js_info, NULL, NULL, NULL, napi_default, NULL},
       {"timings", NULL, js_timings, NULL, NULL, NULL, napi_default, NULL},
       {"destroy", NULL, js_destroy, NULL, NULL, NULL, napi_default, NULL},

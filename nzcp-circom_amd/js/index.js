@@ -78,10 +78,21 @@ class Prover {
     this._busy = p.catch(() => {});
     return p;
   }
-  async proveBatch(wtnsList, opts = {}) {
-    const out = [];
-    for (const w of wtnsList) out.push(await this.prove(w, opts));
-    return out;
+  // Batch of independent witnesses against the resident key (g16_prove_batch: the library overlaps
+  // proof i+1's device work with proof i's tail).  opts.r / opts.s apply to every proof when given.
+  proveBatch(wtnsList, opts = {}) {
+    const ws = wtnsList.map((w) => toBuffer(w, "wtns"));
+    let rs = null;
+    const r = scalarToBuffer(opts.r), s = scalarToBuffer(opts.s);
+    if (r && s) {
+      rs = Buffer.alloc(ws.length * 64);
+      for (let i = 0; i < ws.length; i++) { r.copy(rs, i * 64); s.copy(rs, i * 64 + 32); }
+    }
+    const run = () => native().proveBatch(this._h, ws, rs)
+      .then((list) => list.map(({ proof, pub }) => ({ proof: proofObject(proof), publicSignals: publicSignals(pub) })));
+    const p = this._busy.then(run, run);
+    this._busy = p.catch(() => {});
+    return p;
   }
   close() { if (this._h) { native().destroy(this._h); this._h = null; } }
 }

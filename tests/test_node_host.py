@@ -70,8 +70,10 @@ def test_resident_prover_and_random_blinding(addon):
       const [b, c] = await Promise.all([pv.prove({json.dumps(golden_path('small.wtns'))}), pv.prove({json.dumps(golden_path('small.wtns'))})]);
       let bad = "none";
       try {{ await pv.prove({json.dumps(golden_path('tiny.wtns'))}); }} catch (e) {{ bad = e.message; }}
+      const w = {json.dumps(golden_path('small.wtns'))};
+      const batch = await pv.proveBatch([w, w, w, w, w], {{r: "{meta['r']}", s: "{meta['s']}"}});
       pv.close();
-      console.log(JSON.stringify({{a, b, c, bad, info: null}}));
+      console.log(JSON.stringify({{a, b, c, bad, batch, info: null}}));
     }})();
     """
     r = run_node(script)
@@ -80,6 +82,8 @@ def test_resident_prover_and_random_blinding(addon):
     assert out["a"]["proof"] == meta["proof"] and out["a"]["publicSignals"] == meta["public"]
     assert out["b"]["proof"] != out["c"]["proof"] and out["b"]["publicSignals"] == meta["public"]
     assert out["bad"] == "Invalid witness length. Circuit: 150, witness: 24"
+    assert len(out["batch"]) == 5
+    assert all(x["proof"] == meta["proof"] and x["publicSignals"] == meta["public"] for x in out["batch"])
 
 
 @needs_node
