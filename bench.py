@@ -234,6 +234,7 @@ def main():
     prover = amd.Prover(zkey, device=dev, shard_rank=rank if sharded else 0,
                         shard_count=world if sharded else 1, window_bits=args.window_bits,
                         task_len=args.task_len)
+    zkey_r = zkey if sharded else None      # kept for the replicas measurement below
     if world > 1 or args.no_cpu:
         zkey = None
     info = prover.info
@@ -291,6 +292,26 @@ def main():
     proofs = K * (world if (world > 1 and not sharded) else 1)
     value = proofs / elapsed
 
+    # N > 1, sharded run: also record the throughput reading (BASELINE config 3 across GPUs): every
+    # rank proves `steps` independent proofs on an UNSHARDED handle, no collective -- weak scaling.
+    replicas = None
+    if sharded and zkey_r is not None:
+        rp = amd.Prover(zkey_r, device=dev, window_bits=args.window_bits, task_len=args.task_len)
+        zkey_r = None
+        rp.stage(0, wtns)
+        for _ in range(args.warmup):
+            assert rp.prove_staged_raw(0, r, s, pr, pub) == 0
+        fence()
+        t0r = time.perf_counter()
+        for _ in range(args.steps):
+            assert rp.prove_staged_raw(0, r, s, pr, pub) == 0
+        fence()
+        dtr = time.perf_counter() - t0r
+        tr = torch.tensor([dtr], dtype=torch.float64, device=xdev)
+        dist.all_reduce(tr, op=dist.ReduceOp.MAX)
+        replicas = {"proofs_per_sec": round(world * args.steps / float(tr.item()), 3), "scaling": "weak",
+                    "mode": f"{world} independent unsharded provers, one per GPU, no collective"}
+        rp.close()
     batch = None
     if world == 1 and args.batch_streams > 0:
         batch = batch_leg(amd, args, None, wtns, prover, r, s, log)
@@ -349,6 +370,8 @@ def main():
         }
         if batch is not None:
             out["batch_throughput"] = batch
+        if replicas is not None:
+            out["replicas_throughput"] = replicas
         if world == 1 and not args.no_cpu:
             gpu_bytes = bytes(pr.a) + bytes(pr.b) + bytes(pr.c)
             prover.close()

@@ -364,6 +364,20 @@ static int parse_wtns(const g16_prover* P, const uint8_t* wtns, size_t len, cons
   }
   if ((rc = need_section(f, 2, "wtns", s2))) return rc;
   if (s2.size != (uint64_t)nw * 32) { set_error("wtns: Invalid File format"); return G16_E_FORMAT; }
+  // Witness words must be canonical residues (what every circom witness calculator writes).  The
+  // signed-digit recoding of the MSM assumes scalars below r; reject anything else loudly instead of
+  // producing a wrong proof.  One pass over the top limbs (~1 ms at 1.7 M signals).
+  for (uint32_t i = 0; i < nw; i++) {
+    const uint8_t* w = s2.p + (size_t)i * 32;
+    const uint32_t top = rd32(w + 28);
+    if (top < kR[7]) continue;
+    uint32_t v[8];
+    memcpy(v, w, 32);
+    if (!scalar_lt_r(v)) {
+      set_error("wtns: signal " + std::to_string(i) + " is not reduced modulo the scalar field");
+      return G16_E_FORMAT;
+    }
+  }
   *body = s2.p;
   return G16_OK;
 }

@@ -135,6 +135,12 @@ def test_prove_errors_match_snarkjs(amd):
         prover.prove(b"zkey" + wt[4:])
     with pytest.raises(amd.G16Error, match="not reduced"):
         prover.prove(wt, f.le(b.R), f.le(1))
+    # a witness word >= r is rejected (the recoding assumes canonical scalars)
+    pos2, _ = secs[2][0]
+    bad = bytearray(wt)
+    bad[pos2 + 32 * 5:pos2 + 32 * 6] = f.le(b.R + 3)
+    with pytest.raises(amd.G16Error, match="signal 5 is not reduced"):
+        prover.prove(bytes(bad))
     prover.close()
 
 
