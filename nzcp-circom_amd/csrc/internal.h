@@ -93,7 +93,7 @@ int msm_workspace_create(MsmWorkspace** ws, const MsmInstance* insts, int ninst)
 void msm_workspace_destroy(MsmWorkspace* ws);
 // Runs the MSM of `m` against scalars d_scalars (standard form, 32 B each) and writes the W
 // per-window sums (XYZZ, Montgomery) to host memory out_windows: (W + 1) * msm_point_bytes, the
-// last entry being the unweighted sum of the scalar == 1 points (combine: msm.cuh msm_combine_windows).
+// last entry being the unweighted sum of the scalar == 1 points (combine: msm_combine_windows below).
 float msm_last_accum_ms(const MsmWorkspace* ws);
 int msm_run(const MsmInstance& m, MsmWorkspace* ws, const Fr* d_scalars, uint8_t* out_windows,
             hipStream_t st);

@@ -4,24 +4,28 @@
 // (`G1/G2.multiExpAffine`, pins /root/reference/yarn.lock:408-416, 1132-1138): same inputs
 // (affine Montgomery bases in zkey-section byte layout, 32-byte standard-form scalars), same
 // group element out.  The reference chunks points across web-workers and runs an unsigned-window
-// bucket method per chunk; this is a different schedule for the same sum:
+// bucket method per chunk; this is a different schedule for the same sum (all point arithmetic on
+// the 9x29-bit lazy field, fq29.cuh / ec29.cuh; bases converted once at g16_create):
 //
-//   1. msm_count / msm_scatter: signed c-bit digits (carry-free: one 256-bit add of the constant
-//      K = sum 2^(c-1) 2^(cj) turns signed recoding into plain bit extraction), counting sort of
-//      (point, sign) by bucket key = window*2^(c-1) + |digit|-1.  Wave-ballot aggregation for
-//      the scalar value 1 (~30 % of an NZCP witness) so one hot counter does
-//      not serialise the atomics.
-//   2. msm_accumulate: buckets longer than task_len are split into tasks; one lane per task walks
-//      its slice of the sorted list, gathers the 64/128-byte affine point and mixed-adds it into
-//      an XYZZ accumulator held in VGPRs.
-//   3. msm_bucket_reduce: per window, sum k*S_k by running sums over segments of 16 buckets plus a
-//      short double-and-add for the segment offset.
-//   4. msm_wave_reduce: 64 -> 1 tree per wavefront with __shfl_down of the limbs.
-//   Window sums (W points) go back to the host, which does the c*W doublings (prover.cpp).
+//   1. msm_digits_kernel: signed c-bit digits (carry-free: one 256-bit add of the constant
+//      K = sum 2^(c-1) 2^(cj) turns signed recoding into plain bit extraction), written window-major.
+//      The scalar value 1 (~30 % of an NZCP witness) goes to an extra UNWEIGHTED
+//      pseudo-window spread over its buckets, so there is no giant bucket.
+//   2. msm_sort_kernel<0/1> + msm_hist_* + msm_scan_*: counting sort of (point, sign) by bucket key
+//      = window*2^(c-1) + |digit|-1 with per-workgroup LDS histograms / cursors: no global atomics.
+//   3. msm_task_fill_kernel: buckets are cut into tasks of <= task_len sorted entries.
+//   4. msm_accumulate_kernel: persistent wavefronts over a task queue; a lane walks its task's slice of
+//      the sorted list, gathers the 80/160-byte affine point and mixed-adds it into an XYZZ
+//      accumulator held in VGPRs; a finished lane takes the next task.
+//   5. msm_combine_light/heavy_kernel: task partials -> one sum per bucket (a lane per light bucket,
+//      one wavefront with a __shfl_down tree per heavy bucket).
+//   6. msm_bucket_reduce_kernel: per window, sum k*S_k by running sums over segments of 16 buckets
+//      plus a short double-and-add for the segment offset; msm_wave_reduce_kernel: 64 -> 1 tree per
+//      wavefront with __shfl_down of the limbs; msm_to_canon_kernel: back to the canonical image.
+//   Window sums (W + 1 points) go back to the host, which does the c*W doublings (internal.h).
 //
-// Roofline note: ~10 Fq products per gathered 64-byte point, each ~130
-// v_mad_u64_u32: the kernel is integer-VALU bound by two orders of magnitude, HBM sees one
-// random 64 B read per add.
+// Roofline note: ~3.4k VALU instructions (1.75k v_mad_u64_u32) per
+// gathered point addition, 16 additions per 96 algorithmic bytes: integer-issue bound, not HBM bound.
 #pragma once
 #include "ec29.cuh"
 #include "internal.h"

@@ -471,14 +471,33 @@ static int device_impl(g16_prover* P, uint32_t slot, Partial& out) {
   return collect_ctx(P, P->ctx[0], out);
 }
 
-// Proof assembly on the host: O(1) work, ~1.5k field products.
-static int finish_impl(const KeyPoints* P, const Partial* parts, uint32_t count, const uint8_t* r_in,
-                       const uint8_t* s_in, g16_proof* out) {
+// Proof assembly on the host: O(1) work, in two halves.  The blinding terms that
+// depend only on (r, s) -- r*delta1, s*delta1, (rs)*delta1, s*delta2: four of the six scalar
+// multiplications -- are computed while the GPU is still busy (prepare_blinding, between launch and
+// collect); assemble_proof needs the MSM sums.
+struct Blinding {
   uint32_t r[8], s[8];
+  G1XYZZ r_delta1, s_delta1, neg_rs_delta1;
+  G2XYZZ s_delta2;
+};
+
+static int prepare_blinding(const KeyPoints* P, const uint8_t* r_in, const uint8_t* s_in, Blinding& b) {
   int rc;
-  if (r_in) memcpy(r, r_in, 32); else if ((rc = random_scalar(r))) return rc;
-  if (s_in) memcpy(s, s_in, 32); else if ((rc = random_scalar(s))) return rc;
-  if (!scalar_lt_r(r) || !scalar_lt_r(s)) { set_error("blinding scalar not reduced mod r"); return G16_E_ARG; }
+  if (r_in) memcpy(b.r, r_in, 32); else if ((rc = random_scalar(b.r))) return rc;
+  if (s_in) memcpy(b.s, s_in, 32); else if ((rc = random_scalar(b.s))) return rc;
+  if (!scalar_lt_r(b.r) || !scalar_lt_r(b.s)) { set_error("blinding scalar not reduced mod r"); return G16_E_ARG; }
+  xyzz_mul_scalar(b.r_delta1, P->delta1, b.r);
+  xyzz_mul_scalar(b.s_delta1, P->delta1, b.s);
+  xyzz_mul_scalar(b.s_delta2, P->delta2, b.s);
+  Fr rm, sm;
+  memcpy(rm.v, b.r, 32);
+  memcpy(sm.v, b.s, 32);
+  const Fr rs = fp_from_mont(fp_neg(fp_mul(fp_to_mont(rm), fp_to_mont(sm))));
+  xyzz_mul_scalar(b.neg_rs_delta1, P->delta1, rs.v);
+  return G16_OK;
+}
+
+static int assemble_proof(const KeyPoints* P, const Blinding& b, const Partial* parts, uint32_t count, g16_proof* out) {
   Partial t = parts[0];
   for (uint32_t k = 1; k < count; k++) {
     xyzz_add(t.A, parts[k].A);
@@ -491,18 +510,15 @@ static int finish_impl(const KeyPoints* P, const Partial* parts, uint32_t count,
   // pi_a = alpha1 + sum w_i A_i + r delta1
   G1XYZZ pa = t.A;
   xyzz_madd(pa, P->alpha1);
-  xyzz_mul_scalar(tmp, P->delta1, r);
-  xyzz_add(pa, tmp);
+  xyzz_add(pa, b.r_delta1);
   // pi_b = beta2 + sum w_i B2_i + s delta2
-  G2XYZZ pb = t.B2, tmp2;
+  G2XYZZ pb = t.B2;
   xyzz_madd(pb, P->beta2);
-  xyzz_mul_scalar(tmp2, P->delta2, s);
-  xyzz_add(pb, tmp2);
+  xyzz_add(pb, b.s_delta2);
   // pib1 = beta1 + sum w_i B1_i + s delta1
   G1XYZZ pb1 = t.B1;
   xyzz_madd(pb1, P->beta1);
-  xyzz_mul_scalar(tmp, P->delta1, s);
-  xyzz_add(pb1, tmp);
+  xyzz_add(pb1, b.s_delta1);
   G1Affine a_aff, b1_aff, c_aff;
   G2Affine b_aff;
   xyzz_to_affine(a_aff, pa);
@@ -511,21 +527,24 @@ static int finish_impl(const KeyPoints* P, const Partial* parts, uint32_t count,
   // pi_c = sum_{i>p} w_i C_i + sum P_i H_i + s pi_a + r pib1 - (r s) delta1
   G1XYZZ pc = t.C;
   xyzz_add(pc, t.H);
-  xyzz_mul_scalar(tmp, a_aff, s);
+  xyzz_mul_scalar(tmp, a_aff, b.s);
   xyzz_add(pc, tmp);
-  xyzz_mul_scalar(tmp, b1_aff, r);
+  xyzz_mul_scalar(tmp, b1_aff, b.r);
   xyzz_add(pc, tmp);
-  Fr rm, sm;
-  memcpy(rm.v, r, 32);
-  memcpy(sm.v, s, 32);
-  const Fr rs = fp_from_mont(fp_neg(fp_mul(fp_to_mont(rm), fp_to_mont(sm))));
-  xyzz_mul_scalar(tmp, P->delta1, rs.v);
-  xyzz_add(pc, tmp);
+  xyzz_add(pc, b.neg_rs_delta1);
   xyzz_to_affine(c_aff, pc);
   g1_out(out->a, a_aff);
   g2_out(out->b, b_aff);
   g1_out(out->c, c_aff);
   return G16_OK;
+}
+
+static int finish_impl(const KeyPoints* P, const Partial* parts, uint32_t count, const uint8_t* r_in,
+                       const uint8_t* s_in, g16_proof* out) {
+  Blinding b;
+  int rc = prepare_blinding(P, r_in, s_in, b);
+  if (rc) return rc;
+  return assemble_proof(P, b, parts, count, out);
 }
 
 // ====================================================================== C ABI
@@ -578,10 +597,15 @@ int g16_prove_staged(g16_prover* p, uint32_t slot, const uint8_t r[32], const ui
   if (!p || !out) { set_error("NULL argument"); return G16_E_ARG; }
   std::lock_guard<std::mutex> lk(p->mu);
   if (p->shard_count != 1) { set_error("sharded handle: use g16_prove_partial/g16_prove_finish"); return G16_E_STATE; }
+  if (slot >= p->slot_dev.size() || !p->slot_dev[slot]) { set_error("witness slot not staged"); return G16_E_STATE; }
   Partial part;
-  int rc = device_impl(p, slot, part);
+  Blinding bl;
+  int rc = launch_ctx(p, p->ctx[0], p->slot_dev[slot]);
+  const int rcb = prepare_blinding(&p->kp, r, s, bl);    // host work while the GPU runs
+  if (!rc) rc = collect_ctx(p, p->ctx[0], part);         // always drain what was launched
   if (rc) return rc;
-  rc = finish_impl(&p->kp, &part, 1, r, s, out);
+  if (rcb) return rcb;
+  rc = assemble_proof(&p->kp, bl, &part, 1, out);
   if (!rc && pub && p->nPublic) memcpy(pub, p->slot_pub[slot].data(), (size_t)p->nPublic * 32);
   return rc;
 }
@@ -601,12 +625,15 @@ int g16_prove_batch(g16_prover* p, const uint8_t* const* wtns, const size_t* wtn
   // Software pipeline over the two contexts: while the host waits for, folds and finishes proof i-1,
   // proof i is already running on the GPU.
   const size_t wbytes = (size_t)p->nVars * sizeof(Fr);
+  Blinding bl[g16_prover::kCtx];
+  int bl_rc[g16_prover::kCtx] = {0, 0};
   auto finish_one = [&](size_t i) -> int {
     ProofCtx& c = p->ctx[i % g16_prover::kCtx];
     Partial part;
     int rc = collect_ctx(p, c, part);
     if (rc) return rc;
-    return finish_impl(&p->kp, &part, 1, rs ? rs + i * 64 : nullptr, rs ? rs + i * 64 + 32 : nullptr, &out[i]);
+    if (bl_rc[i % g16_prover::kCtx]) return bl_rc[i % g16_prover::kCtx];
+    return assemble_proof(&p->kp, bl[i % g16_prover::kCtx], &part, 1, &out[i]);
   };
   for (size_t i = 0; i < count; i++) {
     ProofCtx& c = p->ctx[i % g16_prover::kCtx];
@@ -622,6 +649,8 @@ int g16_prove_batch(g16_prover* p, const uint8_t* const* wtns, const size_t* wtn
     G16_HIP(hipMemcpyAsync(c.d_w, body, wbytes, hipMemcpyHostToDevice, c.st));
     if (pub && p->nPublic) memcpy(pub + i * (size_t)p->nPublic * 32, body + 32, (size_t)p->nPublic * 32);
     if ((rc = launch_ctx(p, c, c.d_w))) return rc;
+    bl_rc[i % g16_prover::kCtx] = prepare_blinding(&p->kp, rs ? rs + i * 64 : nullptr, rs ? rs + i * 64 + 32 : nullptr,
+                                                    bl[i % g16_prover::kCtx]);
   }
   for (size_t i = count > (size_t)g16_prover::kCtx ? count - g16_prover::kCtx : 0; i < count; i++) {
     int rc = finish_one(i);
