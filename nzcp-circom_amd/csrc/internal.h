@@ -44,6 +44,8 @@ void ntt_tables_destroy(NttTables& t);
 // in -> natural out with w.
 int ntt_dif_inverse(const NttTables& t, F29* const* vecs, int nvec, hipStream_t st);
 int ntt_dit_forward(const NttTables& t, F29* const* vecs, int nvec, hipStream_t st);
+// ntt_dif_inverse followed by ntt_coset_scale, the table multiply fused into the last pass's store
+int ntt_dif_inverse_coset(const NttTables& t, F29* const* vecs, int nvec, hipStream_t st);
 // x[j] *= coset[j]  (fused 1/N and w_2N^i shift in bit-reversed position order)
 int ntt_coset_scale(const NttTables& t, F29* const* vecs, int nvec, hipStream_t st);
 // operator-level glue: canonical Montgomery(2^256) Fr image <-> the kernels' lazy format (optionally

@@ -9,9 +9,9 @@
 // DIF-then-DIT removes both bit-reversal permutations the reference performs.
 //
 // HBM layout: a vector is N contiguous 40-byte elements (9 x 29-bit limbs + pad).  One launch covers up
-// to 10 butterfly stages: a workgroup stages a 1024-element tile (40 KiB) in LDS, runs the stages
-// with __syncthreads between them and writes the tile back, so a 2^21 transform is 3 passes
-// over HBM instead of 21.  Tiles of later passes are 2^S rows x T columns with T >= 4
+// to 9 butterfly stages: a workgroup stages a 512-element tile (20 KiB, dynamic LDS) and runs the stages
+// with __syncthreads between them, then writes the tile back, so a 2^21 transform is 3 passes (9 + 7 + 5
+// stages) over HBM instead of 21.  Tiles of later passes are 2^S rows x T columns with T >= 4
 // contiguous elements (160 B runs) for coalescing.  Index math validated by the Python model in
 // tests/test_cpu_ntt_plan.py.
 //
@@ -20,14 +20,20 @@
 // products, so every element is weak-reduced on load and after every 3rd DIF stage (sum branch
 // doubles: 1 -> 2 -> 4 -> 8r, subtraction offsets K = 2, 3, 5) or after the 7th DIT stage (+2r per
 // stage), keeping every product input below 16r.
+#include <stdlib.h>
+
 #include "fr29.cuh"
 #include "internal.h"
 
 namespace g16 {
 
-static constexpr int kTileLogMax = 10;
-static constexpr int kMinTb = 2;
+static constexpr int kTileLogCap = 11;   // 2048 elements x 40 B = 80 KiB of LDS at most
 static constexpr int kThreads = 256;
+// tile size / minimum contiguous run, tunable for sweeps: G16_NTT_TILE_LOG (<= 11), G16_NTT_MIN_TB
+static int env_int(const char* name, int dflt) {
+  const char* e = getenv(name);
+  return e ? atoi(e) : dflt;
+}
 
 struct VecPtrs { F29* p[4]; };
 
@@ -35,10 +41,13 @@ __device__ __forceinline__ uint32_t bitrev_dev(uint32_t x, int bits) {
   return bits == 0 ? 0u : (__brev(x) >> (32 - bits));
 }
 
+// `post` (optional): table multiplied into every element on store (the coset/1-over-N table after the
+// last inverse pass), saving one sweep over the vectors.
 __global__ __launch_bounds__(kThreads) void ntt_pass_kernel(VecPtrs vecs, const F29* __restrict__ tw,
                                                             int L, int tile_log, int lo_bits, int S,
-                                                            int tb, int dif) {
-  __shared__ F29 tile[1 << kTileLogMax];
+                                                            int tb, int dif, const F29* __restrict__ post) {
+  extern __shared__ __align__(16) unsigned char ntt_lds[];
+  F29* tile = reinterpret_cast<F29*>(ntt_lds);
   F29* __restrict__ x = vecs.p[blockIdx.y];
   const uint32_t tile_n = 1u << tile_log;
   const uint32_t T = 1u << tb;
@@ -85,7 +94,14 @@ __global__ __launch_bounds__(kThreads) void ntt_pass_kernel(VecPtrs vecs, const 
       __syncthreads();
     }
   }
-  for (uint32_t e = threadIdx.x; e < tile_n; e += kThreads) x[gidx(e)] = tile[e];
+  if (post) {
+    for (uint32_t e = threadIdx.x; e < tile_n; e += kThreads) {
+      const size_t g = gidx(e);
+      x[g] = fr29_mul(tile[e], post[g]);
+    }
+  } else {
+    for (uint32_t e = threadIdx.x; e < tile_n; e += kThreads) x[gidx(e)] = tile[e];
+  }
 }
 
 // tw[i] = w^i
@@ -141,15 +157,25 @@ static Fr host_from_u64(uint64_t v) {
 int ntt_tables_create(NttTables& t, int L, hipStream_t st) {
   if (L < 0 || L > 27) { set_error("domainSize out of range (need 2^0..2^27)"); return G16_E_ARG; }
   t.L = L;
-  t.tile_log = L < kTileLogMax ? L : kTileLogMax;
+  // r01 sweep on MI355X (N = 2^21, three vectors): tile 2^9 = 1.64 ms, 2^10 = 1.84, 2^11 = 2.1, 2^8 = 2.1:
+  // a 20 KiB tile keeps 8 workgroups resident per CU, which matters more than saving a pass.
+  int tile_max = env_int("G16_NTT_TILE_LOG", 9);
+  if (tile_max > kTileLogCap) tile_max = kTileLogCap;
+  if (tile_max < 3) tile_max = 3;
+  int min_tb = env_int("G16_NTT_MIN_TB", 2);
+  if (min_tb < 0) min_tb = 0;
+  if (min_tb > tile_max - 1) min_tb = tile_max - 1;
+  t.tile_log = L < tile_max ? L : tile_max;
   t.passes.clear();
   t.passes.push_back({0, t.tile_log, 0});
   for (int done = t.tile_log; done < L;) {
     int S = L - done;
-    if (S > t.tile_log - kMinTb) S = t.tile_log - kMinTb;
+    if (S > t.tile_log - min_tb) S = t.tile_log - min_tb;
     t.passes.push_back({done, S, t.tile_log - S});
     done += S;
   }
+  G16_HIP(hipFuncSetAttribute((const void*)ntt_pass_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)(sizeof(F29) << kTileLogCap)));
   const size_t N = (size_t)1 << L, half = N > 1 ? N / 2 : 1;
   G16_HIP(hipMalloc(&t.tw_fwd, half * sizeof(F29)));
   G16_HIP(hipMalloc(&t.tw_inv, half * sizeof(F29)));
@@ -174,7 +200,7 @@ void ntt_tables_destroy(NttTables& t) {
   t.L = -1;
 }
 
-static int run_passes(const NttTables& t, F29* const* vecs, int nvec, bool dif, hipStream_t st) {
+static int run_passes(const NttTables& t, F29* const* vecs, int nvec, bool dif, const F29* post_last, hipStream_t st) {
   if (nvec < 1 || nvec > 4) { set_error("ntt: nvec must be 1..4"); return G16_E_ARG; }
   if (t.L == 0) return G16_OK;
   VecPtrs vp{};
@@ -183,19 +209,24 @@ static int run_passes(const NttTables& t, F29* const* vecs, int nvec, bool dif, 
   const int np = (int)t.passes.size();
   for (int k = 0; k < np; k++) {
     const NttPass& p = t.passes[dif ? np - 1 - k : k];
-    ntt_pass_kernel<<<dim3(ntiles, nvec), kThreads, 0, st>>>(vp, dif ? t.tw_inv : t.tw_fwd, t.L,
-                                                             t.tile_log, p.lo_bits, p.S, p.tb,
-                                                             dif ? 1 : 0);
+    ntt_pass_kernel<<<dim3(ntiles, nvec), kThreads, sizeof(F29) << t.tile_log, st>>>(
+        vp, dif ? t.tw_inv : t.tw_fwd, t.L, t.tile_log, p.lo_bits, p.S, p.tb, dif ? 1 : 0,
+        k == np - 1 ? post_last : nullptr);
   }
   G16_HIP(hipGetLastError());
   return G16_OK;
 }
 
 int ntt_dif_inverse(const NttTables& t, F29* const* vecs, int nvec, hipStream_t st) {
-  return run_passes(t, vecs, nvec, true, st);
+  return run_passes(t, vecs, nvec, true, nullptr, st);
+}
+// inverse transform with the coset table (1/N * w_2N^i, bit-reversed order) fused into the last pass
+int ntt_dif_inverse_coset(const NttTables& t, F29* const* vecs, int nvec, hipStream_t st) {
+  if (t.L == 0) return ntt_coset_scale(t, vecs, nvec, st);
+  return run_passes(t, vecs, nvec, true, t.coset, st);
 }
 int ntt_dit_forward(const NttTables& t, F29* const* vecs, int nvec, hipStream_t st) {
-  return run_passes(t, vecs, nvec, false, st);
+  return run_passes(t, vecs, nvec, false, nullptr, st);
 }
 
 int ntt_coset_scale(const NttTables& t, F29* const* vecs, int nvec, hipStream_t st) {

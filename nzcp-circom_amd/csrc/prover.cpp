@@ -424,8 +424,7 @@ static int launch_ctx(g16_prover* P, ProofCtx& c, const Fr* d_w) {
   if ((rc = qap_eval(P->csr, d_w, c.d_a, c.d_b, c.d_c, c.st))) return rc;
   G16_HIP(hipEventRecord(c.ev[3], c.st));
   F29* vecs[3] = {c.d_a, c.d_b, c.d_c};
-  if ((rc = ntt_dif_inverse(P->ntt, vecs, 3, c.st))) return rc;
-  if ((rc = ntt_coset_scale(P->ntt, vecs, 3, c.st))) return rc;
+  if ((rc = ntt_dif_inverse_coset(P->ntt, vecs, 3, c.st))) return rc;   // iNTT + (1/N, w_2N^i) table
   if ((rc = ntt_dit_forward(P->ntt, vecs, 3, c.st))) return rc;
   if ((rc = ntt_join_abc(c.d_a, c.d_b, c.d_c, c.d_p, P->N, c.st))) return rc;
   G16_HIP(hipEventRecord(c.ev[4], c.st));
