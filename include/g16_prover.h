@@ -145,6 +145,12 @@ int g16_synth_setup(uint32_t n_vars, uint32_t n_public, uint32_t n_constraints, 
  * g16_synth_setup uses wseed = seed.  Returns a .wtns image. */
 int g16_synth_witness(uint32_t n_vars, uint32_t n_public, uint32_t n_constraints, uint64_t seed,
                       uint64_t wseed, uint8_t** wtns, size_t* wtns_len);
+/* Test-only trapdoor setup of a REAL circuit: iden3 .r1cs v1 in (what `circom --r1cs`
+ * writes; nPublic = nPubOut + nPubIn), snarkjs-layout .zkey and the verification-key points out (same
+ * layout as g16_synth_setup).  Trapdoor from `seed`.  Lets anyone with circom fabricate a key for the
+ * real nzcp_live R1CS and benchmark its true shape; NOT a ceremony -- the trapdoor is known. */
+int g16_r1cs_setup(const uint8_t* r1cs, size_t r1cs_len, uint64_t seed, int threads, uint8_t** zkey,
+                   size_t* zkey_len, uint8_t** vkey, size_t* vkey_len);
 void g16_free(void* p);
 
 #ifdef __cplusplus

@@ -53,7 +53,7 @@ EXPORTS = ["g16_create", "g16_prove", "g16_prove_batch", "g16_stage_witness", "g
            "g16_prove_partial", "g16_prove_finish", "g16_get_info", "g16_get_timings", "g16_destroy",
            "g16_last_error", "g16_fr_fft", "g16_fr_ifft", "g16_fr_batch_mul", "g16_field_op",
            "g16_ec_add", "g16_g1_multiexp", "g16_g2_multiexp", "g16_synth_setup",
-           "g16_synth_witness", "g16_free", "g16_finish_host", "g16_shard_range"]
+           "g16_synth_witness", "g16_free", "g16_finish_host", "g16_shard_range", "g16_r1cs_setup"]
 
 
 def load():
@@ -91,6 +91,7 @@ def load():
                                     C.POINTER(vp), C.POINTER(sz)]
     lib.g16_synth_witness.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint64, C.c_uint64,
                                       C.POINTER(vp), C.POINTER(sz)]
+    lib.g16_r1cs_setup.argtypes = [C.c_char_p, sz, C.c_uint64, C.c_int, C.POINTER(vp), C.POINTER(sz), C.POINTER(vp), C.POINTER(sz)]
     lib.g16_finish_host.argtypes = [C.c_char_p, sz, C.c_char_p, C.c_uint32, C.c_char_p, C.c_char_p, C.POINTER(Proof)]
     lib.g16_shard_range.argtypes = [C.c_uint32, C.c_int32, C.c_int32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
     lib.g16_shard_range.restype = None
@@ -255,6 +256,39 @@ def synth_setup(n_vars, n_public, n_constraints, seed, threads=0):
     _check(lib.g16_synth_setup(n_vars, n_public, n_constraints, seed, threads, C.byref(z), C.byref(zl),
                                C.byref(w), C.byref(wl), C.byref(v), C.byref(vl)))
     return _take(z, zl), _take(w, wl), _take(v, vl)
+
+
+def r1cs_setup(r1cs, seed, threads=0):
+    """Trapdoor setup of a real .r1cs (bytes) -> (zkey bytes, vkey point bytes)."""
+    lib = load()
+    z, v = C.c_void_p(), C.c_void_p()
+    zl, vl = C.c_size_t(), C.c_size_t()
+    _check(lib.g16_r1cs_setup(r1cs, len(r1cs), seed, threads, C.byref(z), C.byref(zl), C.byref(v), C.byref(vl)))
+    return _take(z, zl), _take(v, vl)
+
+
+_Q = 21888242871839275222246405745257275088696311157297823662689037894645226208583
+
+
+def vkey_json(vkey, n_public):
+    """vkey point bytes (alpha1 | beta2 | gamma2 | delta2 | IC[], affine Montgomery LE) -> the
+    verification_key.json object snarkjs's `groth16.verify` takes (without the redundant vk_alphabeta_12)."""
+    rinv = pow(1 << 256, -1, _Q)
+
+    def fq(b):
+        return str(int.from_bytes(b, "little") * rinv % _Q)
+
+    def g1(b):
+        return ["0", "1", "0"] if b == bytes(64) else [fq(b[:32]), fq(b[32:64]), "1"]
+
+    def g2(b):
+        if b == bytes(128):
+            return [["0", "0"], ["1", "0"], ["0", "0"]]
+        return [[fq(b[0:32]), fq(b[32:64])], [fq(b[64:96]), fq(b[96:128])], ["1", "0"]]
+    return {"protocol": "groth16", "curve": "bn128", "nPublic": n_public,
+            "vk_alpha_1": g1(vkey[0:64]), "vk_beta_2": g2(vkey[64:192]), "vk_gamma_2": g2(vkey[192:320]),
+            "vk_delta_2": g2(vkey[320:448]),
+            "IC": [g1(vkey[448 + 64 * i:512 + 64 * i]) for i in range(n_public + 1)]}
 
 
 def synth_witness(n_vars, n_public, n_constraints, seed, wseed):

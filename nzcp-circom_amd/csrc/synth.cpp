@@ -365,20 +365,16 @@ extern "C" int g16_synth_witness(uint32_t n, uint32_t p, uint32_t m, uint64_t se
   return G16_OK;
 }
 
-extern "C" int g16_synth_setup(uint32_t n, uint32_t p, uint32_t m, uint64_t seed, int threads, uint8_t** zkey,
-                               size_t* zkey_len, uint8_t** wtns, size_t* wtns_len, uint8_t** vkey,
-                               size_t* vkey_len) {
-  if (!zkey || !zkey_len || n < p + 1 || n < 2 || m == 0) { set_error("synth: bad arguments"); return G16_E_ARG; }
+// Trapdoor Groth16 setup of an arbitrary R1CS held in `c` (rows of (signal, Montgomery coefficient)
+// terms): snarkjs zkey layout out, plus the verification-key points.  Trapdoor from stream seed+1.
+static int setup_core(const Circuit& c, uint64_t seed, int threads, uint8_t** zkey, size_t* zkey_len,
+                      uint8_t** vkey, size_t* vkey_len) {
+  const uint32_t n = c.n, p = c.p, m = c.m;
   if (threads <= 0) threads = (int)std::thread::hardware_concurrency();
   if (threads <= 0) threads = 1;
-  Circuit c;
-  c.n = n; c.p = p; c.m = m;
-  gen_circuit(c, seed);
-  std::vector<FrM> w;
-  gen_witness(c, seed, w);
   int L = 0;
   while (((uint64_t)1 << L) < (uint64_t)m + p + 1) L++;
-  if (L > 27) { set_error("synth: circuit too large"); return G16_E_ARG; }
+  if (L > 27) { set_error("setup: circuit too large"); return G16_E_ARG; }
   const size_t N = (size_t)1 << L;
 
   // trapdoor (stream seed+1): tau, alpha, beta, gamma, delta, all non-zero
@@ -494,13 +490,6 @@ extern "C" int g16_synth_setup(uint32_t n, uint32_t p, uint32_t m, uint64_t seed
   memset(p10, 0, sizes[10]);
   *zkey = z.p;
   *zkey_len = z.len;
-
-  if (wtns && wtns_len) {
-    Buf b;
-    write_wtns(w, b);
-    *wtns = b.p;
-    *wtns_len = b.len;
-  }
   if (vkey && vkey_len) {
     // alpha1 | beta2 | gamma2 | delta2 | IC[0..p]   (affine Montgomery LE)
     Buf b;
@@ -515,4 +504,92 @@ extern "C" int g16_synth_setup(uint32_t n, uint32_t p, uint32_t m, uint64_t seed
     *vkey_len = b.len;
   }
   return G16_OK;
+}
+
+extern "C" int g16_synth_setup(uint32_t n, uint32_t p, uint32_t m, uint64_t seed, int threads, uint8_t** zkey,
+                               size_t* zkey_len, uint8_t** wtns, size_t* wtns_len, uint8_t** vkey,
+                               size_t* vkey_len) {
+  if (!zkey || !zkey_len || n < p + 1 || n < 2 || m == 0) { set_error("synth: bad arguments"); return G16_E_ARG; }
+  Circuit c;
+  c.n = n; c.p = p; c.m = m;
+  gen_circuit(c, seed);
+  int rc = setup_core(c, seed, threads, zkey, zkey_len, vkey, vkey_len);
+  if (rc) return rc;
+  if (wtns && wtns_len) {
+    std::vector<FrM> w;
+    gen_witness(c, seed, w);
+    Buf b;
+    write_wtns(w, b);
+    *wtns = b.p;
+    *wtns_len = b.len;
+  }
+  return G16_OK;
+}
+
+// ------------------------------------------------------------------ .r1cs reader
+// iden3 r1cs v1: section 1 header {n8, prime, nWires, nPubOut, nPubIn, nPrvIn, nLabels u64,
+// nConstraints}, section 2 constraints: A, B, C each {nTerms u32, nTerms x (wireId u32, coef n8 LE)}.
+// nPublic of the zkey = nPubOut + nPubIn ([EXT] r1csfile 0.0.35, pin /root/reference/yarn.lock:909-917).
+static int read_r1cs(const uint8_t* buf, size_t len, Circuit& c) {
+  auto bad = [](const char* why) { set_error(std::string("r1cs: ") + why); return G16_E_FORMAT; };
+  if (!buf || len < 12 || memcmp(buf, "r1cs", 4) != 0) { set_error("r1cs: Invalid File format"); return G16_E_FORMAT; }
+  uint32_t version, nsec;
+  memcpy(&version, buf + 4, 4);
+  memcpy(&nsec, buf + 8, 4);
+  if (version > 1) { set_error("Version not supported"); return G16_E_FORMAT; }
+  const uint8_t *s1 = nullptr, *s2 = nullptr;
+  uint64_t l1 = 0, l2 = 0;
+  size_t pos = 12;
+  for (uint32_t i = 0; i < nsec; i++) {
+    if (pos + 12 > len) return bad("truncated section table");
+    uint32_t id; uint64_t sz;
+    memcpy(&id, buf + pos, 4); memcpy(&sz, buf + pos + 4, 8); pos += 12;
+    if (sz > len - pos) return bad("truncated section");
+    if (id == 1 && !s1) { s1 = buf + pos; l1 = sz; }
+    if (id == 2 && !s2) { s2 = buf + pos; l2 = sz; }
+    pos += sz;
+  }
+  if (!s1 || !s2 || l1 < 4 + 32 + 16 + 8 + 4) return bad("missing header or constraint section");
+  uint32_t n8; memcpy(&n8, s1, 4);
+  static const uint32_t Rp[8] = G16_FR_P;
+  if (n8 != 32 || memcmp(s1 + 4, Rp, 32) != 0) return bad("field is not the bn128 scalar field");
+  uint32_t nWires, nPubOut, nPubIn, nPrvIn, nCons;
+  memcpy(&nWires, s1 + 36, 4); memcpy(&nPubOut, s1 + 40, 4); memcpy(&nPubIn, s1 + 44, 4);
+  memcpy(&nPrvIn, s1 + 48, 4); memcpy(&nCons, s1 + 60, 4);
+  (void)nPrvIn;
+  c.n = nWires; c.p = nPubOut + nPubIn; c.m = nCons;
+  if (c.n < c.p + 1 || c.m == 0) return bad("inconsistent header");
+  c.rowA.assign(1, 0); c.rowB.assign(1, 0); c.rowC.assign(1, 0);
+  const uint8_t* q = s2;
+  const uint8_t* end = s2 + l2;
+  std::vector<Term>* dst[3] = {&c.tA, &c.tB, &c.tC};
+  std::vector<uint32_t>* rows[3] = {&c.rowA, &c.rowB, &c.rowC};
+  for (uint32_t r = 0; r < nCons; r++) {
+    for (int k = 0; k < 3; k++) {
+      if (q + 4 > end) return bad("truncated constraint");
+      uint32_t nt; memcpy(&nt, q, 4); q += 4;
+      if ((uint64_t)nt * 36 > (uint64_t)(end - q)) return bad("truncated constraint");
+      for (uint32_t t = 0; t < nt; t++) {
+        uint32_t wire; memcpy(&wire, q, 4);
+        if (wire >= nWires) return bad("wire id out of range");
+        Fr cf; memcpy(cf.v, q + 4, 32);
+        q += 36;
+        dst[k]->push_back({wire, fp_to_mont(cf)});
+      }
+      rows[k]->push_back((uint32_t)dst[k]->size());
+    }
+  }
+  return G16_OK;
+}
+
+// Test-only trapdoor setup of a REAL circuit: .r1cs in, snarkjs-layout .zkey (+ vkey points) out.
+extern "C" int g16_r1cs_setup(const uint8_t* r1cs, size_t r1cs_len, uint64_t seed, int threads, uint8_t** zkey,
+                              size_t* zkey_len, uint8_t** vkey, size_t* vkey_len) {
+  if (!zkey || !zkey_len) { set_error("NULL argument"); return G16_E_ARG; }
+  Circuit c;
+  int rc = read_r1cs(r1cs, r1cs_len, c);
+  if (rc) return rc;
+  uint64_t need = (uint64_t)c.m + c.p + 1;
+  if (need > ((uint64_t)1 << 27)) { set_error("r1cs: circuit too large"); return G16_E_ARG; }
+  return setup_core(c, seed, threads, zkey, zkey_len, vkey, vkey_len);
 }

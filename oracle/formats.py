@@ -85,6 +85,22 @@ def g2_from_lem(b):
     return ((v[0], v[1]), (v[2], v[3]))
 
 
+# ------------------------------------------------------------------ .r1cs (App. A.4)
+def write_r1cs(n_wires, n_pub_out, n_pub_in, rows):
+    """rows: [(A, B, C)] with terms [(wire, coef)]; iden3 r1cs v1 (header, constraints, wire map)."""
+    n_prv = 0
+    hdr = (struct.pack("<I", N8) + le(R) + struct.pack("<IIII", n_wires, n_pub_out, n_pub_in, n_prv) +
+           struct.pack("<Q", n_wires) + struct.pack("<I", len(rows)))
+    body = []
+    for row in rows:
+        for lc in row:
+            body.append(struct.pack("<I", len(lc)))
+            for wire, cf in lc:
+                body.append(struct.pack("<I", wire) + le(cf % R))
+    wmap = b"".join(struct.pack("<Q", i) for i in range(n_wires))
+    return write_binfile("r1cs", 1, [(1, hdr), (2, b"".join(body)), (3, wmap)])
+
+
 # ------------------------------------------------------------------ .wtns (App. A.2)
 def write_wtns(witness):
     hdr = struct.pack("<I", N8) + le(R) + struct.pack("<I", len(witness))

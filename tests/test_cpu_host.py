@@ -101,3 +101,36 @@ def test_no_cpu_fallback(amd):
     with pytest.raises(amd.G16Error) as e:
         amd.multiexp(1, bytes(64), bytes(32))
     assert e.value.code == -4
+
+
+@pytest.mark.parametrize("n,p,m,seed", [(24, 2, 12, 1), (200, 7, 160, 13)])
+def test_r1cs_setup_equals_synth_setup(amd, n, p, m, seed):
+    """the .r1cs reader + trapdoor setup.  The synthetic circuit written as an iden3
+    .r1cs by the oracle and set up by g16_r1cs_setup must give the byte-identical zkey that
+    g16_synth_setup (and the Python oracle setup) produce for the same seed."""
+    _, rows, _ = synth.gen_circuit(n, p, m, seed)
+    r1cs = f.write_r1cs(n, p, 0, rows)
+    zkey, vkey = amd.r1cs_setup(r1cs, seed, 2)
+    zkey2, _, vkey2 = amd.synth_setup(n, p, m, seed, 2)
+    assert zkey == zkey2 and vkey == vkey2
+    # public inputs split between outputs and inputs gives the same nPublic
+    zkey3, _ = amd.r1cs_setup(f.write_r1cs(n, 1, p - 1, rows), seed, 1)
+    assert zkey3 == zkey
+    # the snarkjs-shaped verification key of the setup equals the oracle's
+    rows_w = synth.make(n, p, m, seed)[0]
+    zk, _ = g.setup(n, p, rows_w, g.trapdoor(seed + 1))
+    assert amd.vkey_json(vkey, p) == f.vkey_obj(zk)
+
+
+def test_r1cs_reader_errors(amd):
+    with pytest.raises(amd.G16Error, match="r1cs: Invalid File format"):
+        amd.r1cs_setup(b"zkey" + bytes(40), 1)
+    _, rows, _ = synth.gen_circuit(24, 2, 12, 1)
+    good = f.write_r1cs(24, 2, 0, rows)
+    with pytest.raises(amd.G16Error, match="truncated"):
+        amd.r1cs_setup(good[:len(good) // 2], 1)
+    bad = bytearray(good)
+    secs = f.read_binfile(good, "r1cs", 1)
+    bad[secs[1][0][0] + 4] ^= 1      # another prime
+    with pytest.raises(amd.G16Error, match="not the bn128 scalar field"):
+        amd.r1cs_setup(bytes(bad), 1)
