@@ -401,6 +401,98 @@ static int stage_impl(g16_prover* P, uint32_t slot, const uint8_t* wtns, size_t 
   return G16_OK;
 }
 
+// Proof assembly (SURVEY App. C.2) on the host: O(1) work, in two halves.  The blinding terms that
+// depend only on (r, s) -- r*delta1, s*delta1, (rs)*delta1, s*delta2: four of the six scalar
+// multiplications -- are computed while the GPU is still busy (prepare_blinding, between launch and
+// collect); assemble_proof needs the MSM sums.
+struct Blinding {
+  uint32_t r[8], s[8];
+  G1XYZZ r_delta1, s_delta1, neg_rs_delta1;
+  G2XYZZ s_delta2;
+};
+
+static int prepare_blinding(const KeyPoints* P, const uint8_t* r_in, const uint8_t* s_in, Blinding& b) {
+  int rc;
+  if (r_in) memcpy(b.r, r_in, 32); else if ((rc = random_scalar(b.r))) return rc;
+  if (s_in) memcpy(b.s, s_in, 32); else if ((rc = random_scalar(b.s))) return rc;
+  if (!scalar_lt_r(b.r) || !scalar_lt_r(b.s)) { set_error("blinding scalar not reduced mod r"); return G16_E_ARG; }
+  xyzz_mul_scalar(b.r_delta1, P->delta1, b.r);
+  xyzz_mul_scalar(b.s_delta1, P->delta1, b.s);
+  xyzz_mul_scalar(b.s_delta2, P->delta2, b.s);
+  Fr rm, sm;
+  memcpy(rm.v, b.r, 32);
+  memcpy(sm.v, b.s, 32);
+  const Fr rs = fp_from_mont(fp_neg(fp_mul(fp_to_mont(rm), fp_to_mont(sm))));
+  xyzz_mul_scalar(b.neg_rs_delta1, P->delta1, rs.v);
+  return G16_OK;
+}
+
+// Everything of the proof that does not need the C and H sums: pi_a, pi_b, and the s*pi_a + r*pib1
+// part of pi_c.  Runs on the host while the H-MSM (the last thing to finish) is still on the GPU.
+struct EarlyTail {
+  G1Affine a_aff;
+  G2Affine b_aff;
+  G1XYZZ c_terms;   // s*pi_a + r*pib1 - (rs)*delta1
+};
+static void assemble_early(const KeyPoints* P, const Blinding& b, const G1XYZZ& sumA, const G1XYZZ& sumB1,
+                           const G2XYZZ& sumB2, EarlyTail& e) {
+  // pi_a = alpha1 + sum w_i A_i + r delta1
+  G1XYZZ pa = sumA;
+  xyzz_madd(pa, P->alpha1);
+  xyzz_add(pa, b.r_delta1);
+  // pi_b = beta2 + sum w_i B2_i + s delta2
+  G2XYZZ pb = sumB2;
+  xyzz_madd(pb, P->beta2);
+  xyzz_add(pb, b.s_delta2);
+  // pib1 = beta1 + sum w_i B1_i + s delta1
+  G1XYZZ pb1 = sumB1;
+  xyzz_madd(pb1, P->beta1);
+  xyzz_add(pb1, b.s_delta1);
+  G1Affine b1_aff;
+  xyzz_to_affine(e.a_aff, pa);
+  xyzz_to_affine(b1_aff, pb1);
+  xyzz_to_affine(e.b_aff, pb);
+  G1XYZZ tmp;
+  xyzz_mul_scalar(e.c_terms, e.a_aff, b.s);
+  xyzz_mul_scalar(tmp, b1_aff, b.r);
+  xyzz_add(e.c_terms, tmp);
+  xyzz_add(e.c_terms, b.neg_rs_delta1);
+}
+// pi_c = sum_{i>p} w_i C_i + sum P_i H_i + s pi_a + r pib1 - (r s) delta1
+static void assemble_late(const EarlyTail& e, const G1XYZZ& sumC, const G1XYZZ& sumH, g16_proof* out) {
+  G1XYZZ pc = sumC;
+  xyzz_add(pc, sumH);
+  xyzz_add(pc, e.c_terms);
+  G1Affine c_aff;
+  xyzz_to_affine(c_aff, pc);
+  g1_out(out->a, e.a_aff);
+  g2_out(out->b, e.b_aff);
+  g1_out(out->c, c_aff);
+}
+
+static int assemble_proof(const KeyPoints* P, const Blinding& b, const Partial* parts, uint32_t count, g16_proof* out) {
+  Partial t = parts[0];
+  for (uint32_t k = 1; k < count; k++) {
+    xyzz_add(t.A, parts[k].A);
+    xyzz_add(t.B1, parts[k].B1);
+    xyzz_add(t.C, parts[k].C);
+    xyzz_add(t.H, parts[k].H);
+    xyzz_add(t.B2, parts[k].B2);
+  }
+  EarlyTail e;
+  assemble_early(P, b, t.A, t.B1, t.B2, e);
+  assemble_late(e, t.C, t.H, out);
+  return G16_OK;
+}
+
+static int finish_impl(const KeyPoints* P, const Partial* parts, uint32_t count, const uint8_t* r_in,
+                       const uint8_t* s_in, g16_proof* out) {
+  Blinding b;
+  int rc = prepare_blinding(P, r_in, s_in, b);
+  if (rc) return rc;
+  return assemble_proof(P, b, parts, count, out);
+}
+
 using ProofCtx = g16_prover::ProofCtx;
 
 template <class F>
@@ -442,14 +534,19 @@ static int launch_ctx(g16_prover* P, ProofCtx& c, const Fr* d_w) {
   return G16_OK;
 }
 
-// Wait for context `c` and fold each MSM's window sums (the host folds the early ones while the
-// later ones still run).
-static int collect_ctx(g16_prover* P, ProofCtx& c, Partial& out) {
+// Wait for context `c` and fold each MSM's window sums, in two halves: the witness MSMs (A, B1, B2, C
+// finish long before the H-MSM), then H.  The caller does the H-independent part of the proof
+// assembly between the two.
+static int collect_witness_msms(g16_prover* P, ProofCtx& c, Partial& out) {
   int rc;
   if ((rc = collect_one_msm<FqOps>(P, c, 0, out.A))) return rc;
   if ((rc = collect_one_msm<FqOps>(P, c, 1, out.B1))) return rc;
   if ((rc = collect_one_msm<Fq2Ops>(P, c, 2, out.B2))) return rc;
   if ((rc = collect_one_msm<FqOps>(P, c, 3, out.C))) return rc;
+  return G16_OK;
+}
+static int collect_h_msm(g16_prover* P, ProofCtx& c, Partial& out) {
+  int rc;
   if ((rc = collect_one_msm<FqOps>(P, c, 4, out.H))) return rc;
   G16_HIP(hipEventRecord(c.ev[5], c.st));
   G16_HIP(hipEventSynchronize(c.ev[5]));
@@ -461,6 +558,23 @@ static int collect_ctx(g16_prover* P, ProofCtx& c, Partial& out) {
   P->tm.upload_ms = up;
   return G16_OK;
 }
+static int collect_ctx(g16_prover* P, ProofCtx& c, Partial& out) {
+  int rc = collect_witness_msms(P, c, out);
+  if (rc) return rc;
+  return collect_h_msm(P, c, out);
+}
+// launch-independent second half of a proof on context `c`: collect, and assemble around the H wait
+static int collect_and_assemble(g16_prover* P, ProofCtx& c, const Blinding& bl, g16_proof* out) {
+  Partial part;
+  int rc = collect_witness_msms(P, c, part);
+  EarlyTail e;
+  if (!rc) assemble_early(&P->kp, bl, part.A, part.B1, part.B2, e);   // host work while the H-MSM finishes
+  const int rch = collect_h_msm(P, c, part);                           // always drain what was launched
+  if (rc) return rc;
+  if (rch) return rch;
+  assemble_late(e, part.C, part.H, out);
+  return G16_OK;
+}
 
 // One proof on a staged witness (context 0).
 static int device_impl(g16_prover* P, uint32_t slot, Partial& out) {
@@ -468,82 +582,6 @@ static int device_impl(g16_prover* P, uint32_t slot, Partial& out) {
   int rc = launch_ctx(P, P->ctx[0], P->slot_dev[slot]);
   if (rc) return rc;
   return collect_ctx(P, P->ctx[0], out);
-}
-
-// Proof assembly (SURVEY App. C.2) on the host: O(1) work, in two halves.  The blinding terms that
-// depend only on (r, s) -- r*delta1, s*delta1, (rs)*delta1, s*delta2: four of the six scalar
-// multiplications -- are computed while the GPU is still busy (prepare_blinding, between launch and
-// collect); assemble_proof needs the MSM sums.
-struct Blinding {
-  uint32_t r[8], s[8];
-  G1XYZZ r_delta1, s_delta1, neg_rs_delta1;
-  G2XYZZ s_delta2;
-};
-
-static int prepare_blinding(const KeyPoints* P, const uint8_t* r_in, const uint8_t* s_in, Blinding& b) {
-  int rc;
-  if (r_in) memcpy(b.r, r_in, 32); else if ((rc = random_scalar(b.r))) return rc;
-  if (s_in) memcpy(b.s, s_in, 32); else if ((rc = random_scalar(b.s))) return rc;
-  if (!scalar_lt_r(b.r) || !scalar_lt_r(b.s)) { set_error("blinding scalar not reduced mod r"); return G16_E_ARG; }
-  xyzz_mul_scalar(b.r_delta1, P->delta1, b.r);
-  xyzz_mul_scalar(b.s_delta1, P->delta1, b.s);
-  xyzz_mul_scalar(b.s_delta2, P->delta2, b.s);
-  Fr rm, sm;
-  memcpy(rm.v, b.r, 32);
-  memcpy(sm.v, b.s, 32);
-  const Fr rs = fp_from_mont(fp_neg(fp_mul(fp_to_mont(rm), fp_to_mont(sm))));
-  xyzz_mul_scalar(b.neg_rs_delta1, P->delta1, rs.v);
-  return G16_OK;
-}
-
-static int assemble_proof(const KeyPoints* P, const Blinding& b, const Partial* parts, uint32_t count, g16_proof* out) {
-  Partial t = parts[0];
-  for (uint32_t k = 1; k < count; k++) {
-    xyzz_add(t.A, parts[k].A);
-    xyzz_add(t.B1, parts[k].B1);
-    xyzz_add(t.C, parts[k].C);
-    xyzz_add(t.H, parts[k].H);
-    xyzz_add(t.B2, parts[k].B2);
-  }
-  G1XYZZ tmp;
-  // pi_a = alpha1 + sum w_i A_i + r delta1
-  G1XYZZ pa = t.A;
-  xyzz_madd(pa, P->alpha1);
-  xyzz_add(pa, b.r_delta1);
-  // pi_b = beta2 + sum w_i B2_i + s delta2
-  G2XYZZ pb = t.B2;
-  xyzz_madd(pb, P->beta2);
-  xyzz_add(pb, b.s_delta2);
-  // pib1 = beta1 + sum w_i B1_i + s delta1
-  G1XYZZ pb1 = t.B1;
-  xyzz_madd(pb1, P->beta1);
-  xyzz_add(pb1, b.s_delta1);
-  G1Affine a_aff, b1_aff, c_aff;
-  G2Affine b_aff;
-  xyzz_to_affine(a_aff, pa);
-  xyzz_to_affine(b1_aff, pb1);
-  xyzz_to_affine(b_aff, pb);
-  // pi_c = sum_{i>p} w_i C_i + sum P_i H_i + s pi_a + r pib1 - (r s) delta1
-  G1XYZZ pc = t.C;
-  xyzz_add(pc, t.H);
-  xyzz_mul_scalar(tmp, a_aff, b.s);
-  xyzz_add(pc, tmp);
-  xyzz_mul_scalar(tmp, b1_aff, b.r);
-  xyzz_add(pc, tmp);
-  xyzz_add(pc, b.neg_rs_delta1);
-  xyzz_to_affine(c_aff, pc);
-  g1_out(out->a, a_aff);
-  g2_out(out->b, b_aff);
-  g1_out(out->c, c_aff);
-  return G16_OK;
-}
-
-static int finish_impl(const KeyPoints* P, const Partial* parts, uint32_t count, const uint8_t* r_in,
-                       const uint8_t* s_in, g16_proof* out) {
-  Blinding b;
-  int rc = prepare_blinding(P, r_in, s_in, b);
-  if (rc) return rc;
-  return assemble_proof(P, b, parts, count, out);
 }
 
 // ====================================================================== C ABI
@@ -597,14 +635,15 @@ int g16_prove_staged(g16_prover* p, uint32_t slot, const uint8_t r[32], const ui
   std::lock_guard<std::mutex> lk(p->mu);
   if (p->shard_count != 1) { set_error("sharded handle: use g16_prove_partial/g16_prove_finish"); return G16_E_STATE; }
   if (slot >= p->slot_dev.size() || !p->slot_dev[slot]) { set_error("witness slot not staged"); return G16_E_STATE; }
-  Partial part;
   Blinding bl;
   int rc = launch_ctx(p, p->ctx[0], p->slot_dev[slot]);
   const int rcb = prepare_blinding(&p->kp, r, s, bl);    // host work while the GPU runs
-  if (!rc) rc = collect_ctx(p, p->ctx[0], part);         // always drain what was launched
-  if (rc) return rc;
-  if (rcb) return rcb;
-  rc = assemble_proof(&p->kp, bl, &part, 1, out);
+  if (rc || rcb) {                                       // drain whatever was launched, then report
+    Partial part;
+    if (!rc) (void)collect_ctx(p, p->ctx[0], part);
+    return rc ? rc : rcb;
+  }
+  rc = collect_and_assemble(p, p->ctx[0], bl, out);
   if (!rc && pub && p->nPublic) memcpy(pub, p->slot_pub[slot].data(), (size_t)p->nPublic * 32);
   return rc;
 }
@@ -628,11 +667,12 @@ int g16_prove_batch(g16_prover* p, const uint8_t* const* wtns, const size_t* wtn
   int bl_rc[g16_prover::kCtx] = {0, 0};
   auto finish_one = [&](size_t i) -> int {
     ProofCtx& c = p->ctx[i % g16_prover::kCtx];
-    Partial part;
-    int rc = collect_ctx(p, c, part);
-    if (rc) return rc;
-    if (bl_rc[i % g16_prover::kCtx]) return bl_rc[i % g16_prover::kCtx];
-    return assemble_proof(&p->kp, bl[i % g16_prover::kCtx], &part, 1, &out[i]);
+    if (bl_rc[i % g16_prover::kCtx]) {
+      Partial part;
+      (void)collect_ctx(p, c, part);
+      return bl_rc[i % g16_prover::kCtx];
+    }
+    return collect_and_assemble(p, c, bl[i % g16_prover::kCtx], &out[i]);
   };
   for (size_t i = 0; i < count; i++) {
     ProofCtx& c = p->ctx[i % g16_prover::kCtx];
