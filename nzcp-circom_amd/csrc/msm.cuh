@@ -27,6 +27,8 @@
 // Roofline note: ~3.4k VALU instructions (1.75k v_mad_u64_u32) per
 // gathered point addition, 16 additions per 96 algorithmic bytes: integer-issue bound, not HBM bound.
 #pragma once
+#include <stdlib.h>
+
 #include "ec29.cuh"
 #include "internal.h"
 
@@ -61,7 +63,12 @@ struct MsmWorkspace {
 
 struct U256 { uint32_t v[8]; };
 
-static constexpr uint32_t kSegLen = 16;   // buckets per reduce segment
+static constexpr uint32_t kSegLenDefault = 16;   // buckets per reduce segment (G16_SEG_LEN overrides, sweeps)
+inline uint32_t msm_seg_len() {
+  static uint32_t v = 0;
+  if (!v) { const char* e = getenv("G16_SEG_LEN"); v = e ? (uint32_t)atoi(e) : kSegLenDefault; if (v < 1) v = 1; if (v > 64) v = 64; }
+  return v;
+}
 
 __device__ __forceinline__ uint32_t msm_extract(const uint32_t s[8], int pos, int c) {
   const int word = pos >> 5, off = pos & 31;
@@ -431,14 +438,14 @@ __global__ __launch_bounds__(64) void msm_combine_heavy_kernel(const XYZZ<F>* __
 // seg[j*nseg + g] = sum_{bi in segment g of window j} (bi+1) * S_bi   (j < W);  j == W: sum S_bi
 template <class F>
 __global__ __launch_bounds__(64) void msm_bucket_reduce_kernel(const XYZZ<F>* __restrict__ bsum, uint32_t B,
-                                                               uint32_t nseg, uint32_t W,
+                                                               uint32_t nseg, uint32_t W, uint32_t seg_len,
                                                                XYZZ<F>* __restrict__ seg) {
   const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
   if (tid >= (W + 1) * nseg) return;
   const uint32_t j = tid / nseg, g = tid % nseg;
   const bool plain = (j == W);   // the "ones" pseudo-window: plain sum of its buckets
-  const uint32_t lo = g * kSegLen;
-  const uint32_t hi = (lo + kSegLen < B) ? lo + kSegLen : B;
+  const uint32_t lo = g * seg_len;
+  const uint32_t hi = (lo + seg_len < B) ? lo + seg_len : B;
   XYZZ<F> run, acc;
   x29_set_inf(run);
   x29_set_inf(acc);
@@ -513,7 +520,8 @@ int msm_launch_t(const MsmInstance& m, MsmWorkspace* ws, const Fr* d_scalars, hi
   using CPT = XYZZ<typename F::CanonOps>;
   ws->out_bytes = (size_t)WT * sizeof(CPT);
   if (m.n == 0) return G16_OK;
-  const uint32_t nseg = (B + kSegLen - 1) / kSegLen;
+  const uint32_t seg_len = msm_seg_len();
+  const uint32_t nseg = (B + seg_len - 1) / seg_len;
   U256 K;
   msm_make_K(m.c, m.W, K);
   const uint32_t nblk = (m.n + 255) / 256;
@@ -555,7 +563,7 @@ int msm_launch_t(const MsmInstance& m, MsmWorkspace* ws, const Fr* d_scalars, hi
                                                              (PT*)ws->d_bsum, ws->d_heavy, ws->max_heavy);
   msm_combine_heavy_kernel<F><<<1024, 64, 0, st>>>((const PT*)ws->d_partial, ws->d_toff, (PT*)ws->d_bsum,
                                                    ws->d_heavy, ws->max_heavy);
-  msm_bucket_reduce_kernel<F><<<(WT * nseg + 63) / 64, 64, 0, st>>>((const PT*)ws->d_bsum, B, nseg, W,
+  msm_bucket_reduce_kernel<F><<<(WT * nseg + 63) / 64, 64, 0, st>>>((const PT*)ws->d_bsum, B, nseg, W, seg_len,
                                                                    (PT*)ws->d_seg);
   // tree: d_seg (nseg per window) -> ... -> 1 per window, ping-pong between d_red halves
   PT* cur = (PT*)ws->d_seg;

@@ -100,7 +100,7 @@ int msm_workspace_create(MsmWorkspace** out, const MsmInstance* insts, int ninst
     const uint64_t nb = (uint64_t)(m.W + 1) * m.nbuckets;   // + the ones window
     const uint64_t entries = (uint64_t)m.n * m.W;
     const uint64_t tasks = nb + entries / m.task_len + 64;
-    const uint64_t nseg = (m.nbuckets + kSegLen - 1) / kSegLen;
+    const uint64_t nseg = (m.nbuckets + msm_seg_len() - 1) / msm_seg_len();
     const size_t pb = m.curve == 2 ? sizeof(G2XYZZ29) : sizeof(G1XYZZ29);   // device-side (lazy) points
     const size_t cpb = msm_point_bytes(m.curve);                             // canonical, host-visible
     if (entries > ws->max_entries) ws->max_entries = (uint32_t)entries;
