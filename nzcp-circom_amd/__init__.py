@@ -108,7 +108,8 @@ def _check(rc):
 
 def _take(ptr, n):
     """Copy a malloc'd buffer into bytes and free it."""
-    data = C.string_at(ptr.value, n.value)
+    # (string_at takes a C int size: a 2^22-constraint zkey is > 2 GiB)
+    data = bytes((C.c_char * n.value).from_address(ptr.value)) if n.value else b""
     load().g16_free(ptr)
     return data
 

@@ -1,0 +1,147 @@
+"""GPU parity at BASELINE.json's FULL sizes, where the big-int oracle cannot
+follow.  Checks are the size-independent ones the domain offers:
+
+  * the proof is accepted by the Groth16 pairing equation against the setup's verification key
+    (e(-A,B) e(alpha,beta) e(vk_x,gamma) e(C,delta) == 1, oracle/bn254.py),
+  * bit-equality with the oracle's C prover (oracle/c) on the SAME (zkey, wtns, r, s),
+  * public.json == w[1..p] of the witness,
+  * linearity of the blinding: proofs of one witness under (r, s) and (r, s + d) have
+    pi_b' = pi_b + d.delta2, and both verify,
+  * determinism: a second run gives the same bytes; batch == one-by-one; point-range shards == whole.
+Inputs are shape-matched synthetic circuits (the real circuit cannot be compiled offline)."""
+import ctypes
+import hashlib
+import os
+
+import pytest
+
+import bn254 as b
+import formats as f
+import groth16 as g
+import synth
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+
+P_NZCP = 513
+WTNS_BODY = 12 + (12 + 40) + 12     # binfile header, section 1 (n8, r, nWitness), section 2 header
+
+
+def _oracle_c():
+    path = os.path.join(ROOT, "oracle", "_build", "libg16oracle.so")
+    if not os.path.exists(path):
+        pytest.skip("oracle/_build/libg16oracle.so not built")
+    lib = ctypes.CDLL(path)
+    lib.g16o_prove.argtypes = [ctypes.c_char_p, ctypes.c_size_t, ctypes.c_char_p, ctypes.c_size_t,
+                               ctypes.c_char_p, ctypes.c_char_p, ctypes.c_char_p, ctypes.c_char_p, ctypes.c_int]
+    return lib
+
+
+def _rs(seed):
+    rng = synth.Xoshiro(seed + 2)
+    return rng.rand_fr(), rng.rand_fr()
+
+
+def _vk(vkey, p=P_NZCP):
+    return {"alpha1": f.g1_from_lem(vkey[0:64]), "beta2": f.g2_from_lem(vkey[64:192]),
+            "gamma2": f.g2_from_lem(vkey[192:320]), "delta2": f.g2_from_lem(vkey[320:448]),
+            "IC": [f.g1_from_lem(vkey[448 + 64 * i:512 + 64 * i]) for i in range(p + 1)]}
+
+
+def _points(proof):
+    return f.g1_from_obj(proof["pi_a"]), f.g2_from_obj(proof["pi_b"]), f.g1_from_obj(proof["pi_c"])
+
+
+def _pub_of(wtns, p=P_NZCP):
+    return [str(f.from_le(wtns[WTNS_BODY + 32 * i:WTNS_BODY + 32 * (i + 1)])) for i in range(1, p + 1)]
+
+
+def _verifies(vk, pub, proof):
+    return g.verify(vk, [int(x) for x in pub], _points(proof))
+
+
+@pytest.mark.parametrize("n", [900_000, 1_700_000])
+def test_config2_nzcp_live_shape(amd, n):
+    """config 2: n = nConstraints in {0.9 M, 1.7 M}, p = 513."""
+    seed = synth.SEED_NZCP
+    zkey, wtns, vkey = amd.synth_setup(n, P_NZCP, n, seed)
+    vk = _vk(vkey)
+    r, s = _rs(seed)
+    prover = amd.Prover(zkey)
+    assert prover.info.domain_size == (1 << 20 if n == 900_000 else 1 << 21)
+    proof, pub = prover.prove(wtns, f.le(r), f.le(s))
+    assert pub == _pub_of(wtns)
+    assert _verifies(vk, pub, proof)
+    # same bytes from the oracle's C prover
+    olib = _oracle_c()
+    out = ctypes.create_string_buffer(256)
+    opub = ctypes.create_string_buffer(P_NZCP * 32)
+    assert olib.g16o_prove(zkey, len(zkey), wtns, len(wtns), f.le(r), f.le(s), out, opub, os.cpu_count() or 1) == 0
+    pr = amd.Proof()
+    gpub = ctypes.create_string_buffer(P_NZCP * 32)
+    prover.stage(0, wtns)
+    assert prover.prove_staged_raw(0, f.le(r), f.le(s), pr, gpub) == 0
+    assert bytes(pr.a) + bytes(pr.b) + bytes(pr.c) == out.raw
+    assert gpub.raw == opub.raw
+    # determinism + blinding linearity
+    proof2, _ = prover.prove(wtns, f.le(r), f.le(s))
+    assert proof2 == proof
+    d = 99
+    proof3, _ = prover.prove(wtns, f.le(r), f.le((s + d) % b.R))
+    assert proof3["pi_a"] == proof["pi_a"]
+    assert b.G2.add(_points(proof)[1], b.G2.mul(vk["delta2"], d)) == _points(proof3)[1]
+    assert _verifies(vk, pub, proof3)
+    prover.close()
+
+
+def test_config3_batch_throughput_mode(amd):
+    """config 3 (bounded): one resident key, a batch of independent witnesses through g16_prove_batch;
+    every proof equals the one-by-one result, first and last are pairing-verified."""
+    n, seed, count = 900_000, synth.SEED_NZCP, 6
+    zkey, wtns0, vkey = amd.synth_setup(n, P_NZCP, n, seed)
+    vk = _vk(vkey)
+    wts = [wtns0] + [amd.synth_witness(n, P_NZCP, n, seed, seed + 100 + i) for i in range(1, count)]
+    assert len({hashlib.sha256(w).digest() for w in wts}) == count
+    lib = amd.load()
+    prover = amd.Prover(zkey)
+    rs = [_rs(seed + i) for i in range(count)]
+    arr = (ctypes.c_char_p * count)(*wts)
+    lens = (ctypes.c_size_t * count)(*[len(w) for w in wts])
+    rsbuf = b"".join(f.le(r) + f.le(s) for r, s in rs)
+    proofs = (amd.Proof * count)()
+    pubs = ctypes.create_string_buffer(count * P_NZCP * 32)
+    rc = lib.g16_prove_batch(prover._h, arr, lens, count, rsbuf, proofs, pubs)
+    assert rc == 0, lib.g16_last_error()
+    for i in range(count):
+        obj = amd.proof_to_obj(proofs[i])
+        raw = pubs.raw[i * P_NZCP * 32:(i + 1) * P_NZCP * 32]
+        pub = [str(f.from_le(raw[k * 32:(k + 1) * 32])) for k in range(P_NZCP)]
+        assert pub == _pub_of(wts[i])
+        one, _ = prover.prove(wts[i], f.le(rs[i][0]), f.le(rs[i][1]))
+        assert obj == one
+        if i in (0, count - 1):
+            assert _verifies(vk, pub, obj)
+    prover.close()
+
+
+def test_config5_stress_2_22(amd):
+    """config 5: N = 2^22 (n = nConstraints = 2^22 - 514), the largest configuration in BASELINE.json."""
+    n = (1 << 22) - (P_NZCP + 1)
+    seed = synth.SEED_NZCP + 5
+    zkey, wtns, vkey = amd.synth_setup(n, P_NZCP, n, seed)
+    vk = _vk(vkey)
+    r, s = _rs(seed)
+    prover = amd.Prover(zkey)
+    assert prover.info.domain_size == 1 << 22
+    proof, pub = prover.prove(wtns, f.le(r), f.le(s))
+    assert pub == _pub_of(wtns)
+    assert _verifies(vk, pub, proof)
+    prover.close()
+    # config 4's sharding at this size: 3 uneven point-range shards on the same GPU == the whole proof
+    parts = []
+    for k in range(3):
+        sh = amd.Prover(zkey, shard_rank=k, shard_count=3)
+        sh.stage(0, wtns)
+        parts.append(sh.prove_partial(0))
+        sh.close()
+    assert amd.finish_host(zkey, parts, f.le(r), f.le(s)) == proof
