@@ -82,6 +82,29 @@ template <class F> G16_HD void x29_madd(XYZZ<F>& acc, const Affine<F>& q) {
   acc.zzz = F::mul(acc.zzz, PPP);
 }
 
+// acc <- acc + q by the plain madd-2008-s formula, no exceptional cases: the hot loop of the bucket
+// accumulation.  Returns true when the result may be wrong -- x(q) == x(acc) (doubling or cancellation,
+// caught by the low-limb filter on P, which also fires on a 2^-26 fraction of ordinary additions) -- and
+// the caller then recomputes the whole task with x29_madd (msm_redo_kernel).  acc must not be infinity
+// (a task starts from its first point; infinity only arises from a cancellation, which is flagged).
+template <class F> G16_HD bool x29_madd_fast(XYZZ<F>& acc, const Affine<F>& q) {
+  using T = typename F::T;
+  const T U2 = F::mul(q.x, acc.zz);
+  const T S2 = F::mul(q.y, acc.zzz);
+  const T P = F::template sub<6>(U2, acc.x);
+  const T R = F::template sub<4>(S2, acc.y);
+  const bool suspicious = F::template maybe_zero<7>(P);
+  const T PP = F::sqr(P);
+  const T PPP = F::mul(P, PP);
+  const T Qv = F::mul(acc.x, PP);
+  const T X3 = F::template sub<4>(F::sqr(R), F::add(PPP, F::add(Qv, Qv)));
+  acc.y = F::template sub<2>(F::mul(R, F::template sub<6>(Qv, X3)), F::mul(acc.y, PPP));
+  acc.x = X3;
+  acc.zz = F::mul(acc.zz, PP);
+  acc.zzz = F::mul(acc.zzz, PPP);
+  return suspicious;
+}
+
 // acc <- acc + q, both XYZZ
 template <class F> G16_HD void x29_add(XYZZ<F>& acc, const XYZZ<F>& q) {
   using T = typename F::T;

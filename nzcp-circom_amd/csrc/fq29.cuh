@@ -81,6 +81,18 @@ template <class C = Fq29C> G16_HD F29 f29_one() {
 
 // full carry ripple: limbs 0..7 below 2^29 afterwards (inputs: any limbs whose running sums fit 32 bits)
 G16_HD void f29_carry(F29& a) {
+#if defined(G16_F29_PAR_CARRY)
+  {  // experiment: one parallel carry step -- limbs end below 2^29 + 2^3 instead of exactly normalised
+    uint32_t c[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) c[i] = a.l[i] >> 29;
+#pragma unroll
+    for (int i = 0; i < 8; i++) a.l[i] &= kM29;
+#pragma unroll
+    for (int i = 0; i < 8; i++) a.l[i + 1] += c[i];
+    return;
+  }
+#endif
   uint32_t c = 0;
 #pragma unroll
   for (int i = 0; i < 8; i++) {
@@ -115,6 +127,68 @@ template <int K, class C = Fq29C> G16_HD F29 f29_neg(const F29& b) {
 #pragma unroll
   for (int i = 0; i < 9; i++) r.l[i] = C::template KP<K>::V[i] - b.l[i];
   f29_carry(r);
+  return r;
+}
+
+// Operand-scanning (row-wise) Montgomery product: the same 162 multiply-adds as f29_mul below, but each
+// goes to a DIFFERENT 64-bit column accumulator than its neighbours (18 short dependency chains instead
+// of 17 long ones), so one wavefront keeps several v_mad_u64_u32 in flight.  Column bound: 9 a*b terms
+// + 9 m*p terms < 2^58 each + a carry < 2^36, below 2^63.
+template <class C = Fq29C> G16_HD F29 f29_mul_rows(const F29& a, const F29& b) {
+  G16_F29_ASSERT_LIMBS(a); G16_F29_ASSERT_LIMBS(b);
+  uint64_t t[18];
+#pragma unroll
+  for (int j = 0; j < 9; j++) t[j] = (uint64_t)a.l[0] * b.l[j];
+#pragma unroll
+  for (int j = 9; j < 18; j++) t[j] = 0;
+#pragma unroll
+  for (int i = 0; i < 9; i++) {
+    if (i > 0) {
+#pragma unroll
+      for (int j = 0; j < 9; j++) t[i + j] += (uint64_t)a.l[i] * b.l[j];
+    }
+    const uint32_t m = ((uint32_t)t[i] * C::INV) & kM29;
+#pragma unroll
+    for (int j = 0; j < 9; j++) t[i + j] += (uint64_t)m * C::P[j];
+    t[i + 1] += t[i] >> 29;
+  }
+  F29 r;
+#pragma unroll
+  for (int k = 9; k < 17; k++) {
+    r.l[k - 9] = (uint32_t)t[k] & kM29;
+    t[k + 1] += t[k] >> 29;
+  }
+  r.l[8] = (uint32_t)t[17];
+  G16_F29_ASSERT_BOUND(r);
+  return r;
+}
+template <class C = Fq29C> G16_HD F29 f29_sqr_rows(const F29& a) {
+  G16_F29_ASSERT_LIMBS(a);
+  uint64_t t[18];
+#pragma unroll
+  for (int j = 0; j < 18; j++) t[j] = 0;
+#pragma unroll
+  for (int i = 0; i < 9; i++) {
+    const uint32_t a2 = a.l[i] << 1;
+    t[2 * i] += (uint64_t)a.l[i] * a.l[i];
+#pragma unroll
+    for (int j = i + 1; j < 9; j++) t[i + j] += (uint64_t)a2 * a.l[j];
+  }
+#pragma unroll
+  for (int i = 0; i < 9; i++) {
+    const uint32_t m = ((uint32_t)t[i] * C::INV) & kM29;
+#pragma unroll
+    for (int j = 0; j < 9; j++) t[i + j] += (uint64_t)m * C::P[j];
+    t[i + 1] += t[i] >> 29;
+  }
+  F29 r;
+#pragma unroll
+  for (int k = 9; k < 17; k++) {
+    r.l[k - 9] = (uint32_t)t[k] & kM29;
+    t[k + 1] += t[k] >> 29;
+  }
+  r.l[8] = (uint32_t)t[17];
+  G16_F29_ASSERT_BOUND(r);
   return r;
 }
 
@@ -412,8 +486,13 @@ __device__ __forceinline__ F29 f29_sqr_mul_call(const F29& a, const F29& c, cons
 #define G16_F29_MUL2(a, b, c, d) f29_mul2_call(a, b, c, d)
 #define G16_F29_SQR_MUL(a, c, d) f29_sqr_mul_call(a, c, d)
 #else
+#if defined(G16_F29_ROWS)
+#define G16_F29_MUL(a, b) f29_mul_rows(a, b)
+#define G16_F29_SQR(a) f29_sqr_rows(a)
+#else
 #define G16_F29_MUL(a, b) f29_mul(a, b)
 #define G16_F29_SQR(a) f29_sqr(a)
+#endif
 #define G16_F29_MUL2(a, b, c, d) f29_mul2(a, b, c, d)
 #define G16_F29_SQR_MUL(a, c, d) f29_sqr_mul(a, c, d)
 #endif
@@ -428,7 +507,7 @@ struct Fq29Ops {
   using T = F29;
   using Canon = Fq;   // canonical twin (fp.cuh)
   using CanonOps = FqOps;
-  static constexpr int kAccumWavesPerSimd = 4;   // msm_accumulate: fit 128 VGPRs (5 dwords spill)
+  static constexpr int kAccumWavesPerSimd = 4;   // msm_accumulate: fits 128 VGPRs
   static G16_HD T zero() { return f29_zero(); }
   static G16_HD T one() { return f29_one(); }
   static G16_HD bool is_literal_zero(const T& x) { return f29_is_literal_zero(x); }

@@ -74,6 +74,7 @@ struct MsmConfig {
   int c = 0;           // window bits (0 = choose from n)
   int task_len = 0;    // max sorted entries per accumulation task (0 = default)
   bool dense = true;   // scalars uniform in Fr (H) vs NZCP witness mix (~1/3 full-width)
+  int precomp = 0;     // window precomputation factor (0 = default, 1 = none): see MsmInstance::pf
 };
 struct MsmWorkspace;   // opaque, msm.cuh
 // Fixed-base-set MSM instance: bases resident in HBM, infinity points compacted away.
@@ -82,7 +83,13 @@ struct MsmInstance {
   uint32_t n = 0;              // non-infinity bases
   void* d_bases = nullptr;     // Affine<F>[n] (Montgomery)
   uint32_t* d_src = nullptr;   // scalar index of base i (into the scalar vector handed to run)
-  int c = 0, W = 0;
+  // Window precomputation: the base table also holds 2^(c W k) * P_i for k = 1..pf-1 (computed once at
+  // create), so scalar window j = k W + r of point i lands in row r as entry k n + i: only W = ceil(Ws / pf)
+  // rows of buckets are reduced instead of Ws, for the same number of bucket additions.
+  int c = 0, W = 0;            // window bits; ROWS of buckets (= output window sums, Horner on the host)
+  int Ws = 0;                  // scalar windows = ceil(256 / c)
+  uint32_t pf = 1;             // precomputation factor
+  uint32_t n_ext = 0;          // pf * n = entries per row = points in d_bases
   uint32_t nbuckets = 0;       // per window = 2^(c-1)
   uint32_t task_len = 0;
 };
@@ -97,6 +104,11 @@ void msm_workspace_destroy(MsmWorkspace* ws);
 // per-window sums (XYZZ, Montgomery) to host memory out_windows: (W + 1) * msm_point_bytes, the
 // last entry being the unweighted sum of the scalar == 1 points (combine: msm_combine_windows below).
 float msm_last_accum_ms(const MsmWorkspace* ws);
+// accumulate kernel of the next msm_launch on `ws`: wait for `accum_gate` first (nullptr = none); persistent
+// grid of `waves_per_simd` wavefronts per SIMD (0 = full occupancy)
+void msm_set_schedule(MsmWorkspace* ws, hipEvent_t accum_gate, uint32_t waves_per_simd);
+hipEvent_t msm_accum_done_event(MsmWorkspace* ws);   // recorded after the accumulate kernel of the last launch
+float msm_accum_event_offset_ms(MsmWorkspace* ws, hipEvent_t base, int which);   // G16_TRACE_HOST timeline
 int msm_run(const MsmInstance& m, MsmWorkspace* ws, const Fr* d_scalars, uint8_t* out_windows,
             hipStream_t st);
 // The same split in two so several MSMs can be in flight on different streams: msm_launch only

@@ -15,6 +15,26 @@ static int msm_convert_bases_g1(const void* in, void* out, uint32_t n) {
   return G16_OK;
 }
 
+int msm_precompute_g2(const void* in, void* out, uint32_t n, int ndbl);
+static int msm_precompute_g1(const void* in, void* out, uint32_t n, int ndbl) {
+  msm_precompute_kernel<FqOps><<<(n + 255) / 256, 256>>>((const G1Affine*)in, (G1Affine*)out, n, ndbl);
+  G16_HIP(hipGetLastError());
+  G16_HIP(hipDeviceSynchronize());
+  return G16_OK;
+}
+
+// window precomputation factor: MsmConfig::precomp, else G16_PRECOMP, else the default
+static uint32_t choose_pf(const MsmConfig& cfg, int Ws) {
+  int pf = cfg.precomp;
+  if (pf <= 0) {
+    const char* e = getenv("G16_PRECOMP");
+    pf = e ? atoi(e) : 1;
+  }
+  if (pf < 1) pf = 1;
+  if (pf > Ws) pf = Ws;
+  return (uint32_t)pf;
+}
+
 static int choose_c(uint32_t n) {
   // minimise W * (n + 2.5 * 2^(c-1)) over c in [4, 16], W = ceil(256 / c).  For large n skip window
   // sizes whose TOP window holds only 1..5 bits of the 254-bit scalar (c = 14, 12, 11, 10, 9, 7, 6, 4):
@@ -58,27 +78,44 @@ int msm_instance_create(MsmInstance& m, int curve, const uint8_t* bases_host, ui
   const uint32_t n_eff = cfg.dense ? m.n : m.n / 3 + 1;
   m.c = cfg.c ? cfg.c : choose_c(n_eff ? n_eff : 1);
   if (m.c < 2 || m.c > 16) { set_error("msm: window bits must be in [2,16]"); return G16_E_ARG; }
-  m.W = (256 + m.c - 1) / m.c;
+  m.Ws = (256 + m.c - 1) / m.c;
+  m.pf = choose_pf(cfg, m.Ws);
+  m.W = (m.Ws + (int)m.pf - 1) / (int)m.pf;
+  m.pf = (uint32_t)((m.Ws + m.W - 1) / m.W);   // drop empty trailing levels (Ws = 16, pf = 5 -> W = 4, pf = 4)
+  m.n_ext = m.pf * m.n;
+  if ((uint64_t)m.pf * m.n >= 0x7fffffffull) { set_error("msm: too many precomputed bases"); return G16_E_ARG; }
   m.nbuckets = 1u << (m.c - 1);
   // Task length: enough tasks to fill ~256k lanes (256 CUs x 4 SIMDs x 4 waves x 64), within [16, 256].
   if (cfg.task_len) {
     m.task_len = (uint32_t)cfg.task_len;
   } else {
-    const uint64_t entries = (uint64_t)n_eff * m.W;
+    const uint64_t entries = (uint64_t)n_eff * m.Ws;
     uint64_t t = entries / 262144;
     m.task_len = (uint32_t)(t < 16 ? 16 : (t > 32 ? 32 : t));   // short tasks: small drain tail (sweep r01)
   }
   if (m.n) {
     // upload the canonical image, convert once on the device to the kernels' 9x29 representation
     void* tmp = nullptr;
-    const size_t lazy_bytes = (size_t)m.n * (curve == 2 ? sizeof(G2Affine29) : sizeof(G1Affine29));
+    void* tmp2 = nullptr;
+    const size_t lazy_pt = curve == 2 ? sizeof(G2Affine29) : sizeof(G1Affine29);
     G16_HIP(hipMalloc(&tmp, packed.size()));
-    G16_HIP(hipMalloc(&m.d_bases, lazy_bytes));
+    if (m.pf > 1) G16_HIP(hipMalloc(&tmp2, packed.size()));
+    G16_HIP(hipMalloc(&m.d_bases, (size_t)m.n_ext * lazy_pt));
     G16_HIP(hipMalloc(&m.d_src, (size_t)m.n * 4));
     G16_HIP(hipMemcpy(tmp, packed.data(), packed.size(), hipMemcpyHostToDevice));
     G16_HIP(hipMemcpy(m.d_src, src.data(), (size_t)m.n * 4, hipMemcpyHostToDevice));
-    int rc = curve == 2 ? msm_convert_bases_g2(tmp, m.d_bases, m.n) : msm_convert_bases_g1(tmp, m.d_bases, m.n);
+    int rc = G16_OK;
+    for (uint32_t k = 0; k < m.pf && !rc; k++) {
+      // level k = 2^(c W) * level k-1 (canonical, ping-pong between tmp and tmp2), then to the lazy format
+      void* cur = (k & 1) ? tmp2 : tmp;
+      void* nxt = (k & 1) ? tmp : tmp2;
+      void* dst = (uint8_t*)m.d_bases + (size_t)k * m.n * lazy_pt;
+      rc = curve == 2 ? msm_convert_bases_g2(cur, dst, m.n) : msm_convert_bases_g1(cur, dst, m.n);
+      if (!rc && k + 1 < m.pf)
+        rc = curve == 2 ? msm_precompute_g2(cur, nxt, m.n, m.c * m.W) : msm_precompute_g1(cur, nxt, m.n, m.c * m.W);
+    }
     (void)hipFree(tmp);
+    if (tmp2) (void)hipFree(tmp2);
     if (rc) return rc;
   }
   return G16_OK;
@@ -98,8 +135,8 @@ int msm_workspace_create(MsmWorkspace** out, const MsmInstance* insts, int ninst
   for (int i = 0; i < ninst; i++) {
     const MsmInstance& m = insts[i];
     const uint64_t nb = (uint64_t)(m.W + 1) * m.nbuckets;   // + the ones window
-    const uint64_t entries = (uint64_t)m.n * m.W;
-    const uint64_t tasks = nb + entries / m.task_len + 64;
+    const uint64_t entries = (uint64_t)m.n * m.Ws;
+    const uint64_t tasks = nb + entries / (m.task_len >= 16 ? m.task_len / 4 : 4) + 64;   // worst case of the graded lengths
     const uint64_t nseg = (m.nbuckets + msm_seg_len() - 1) / msm_seg_len();
     const size_t pb = m.curve == 2 ? sizeof(G2XYZZ29) : sizeof(G1XYZZ29);   // device-side (lazy) points
     const size_t cpb = msm_point_bytes(m.curve);                             // canonical, host-visible
@@ -124,10 +161,10 @@ int msm_workspace_create(MsmWorkspace** out, const MsmInstance* insts, int ninst
     if (per_cu > 2) per_cu = 2;        // 1024-thread workgroups: at most 2 per CU
     if (per_cu < 1) per_cu = 1;
     uint32_t chunks = (256 * per_cu + WT - 1) / WT;
-    const uint32_t max_chunks = m.n / 4096 + 1;
+    const uint32_t max_chunks = m.n_ext / 4096 + 1;
     if (chunks > max_chunks) chunks = max_chunks;
     if (chunks > ws->chunks) ws->chunks = chunks;
-    if ((size_t)WT * m.n > dig_words) dig_words = (size_t)WT * m.n;
+    if ((size_t)WT * m.n_ext > dig_words) dig_words = (size_t)WT * m.n_ext;
     if ((size_t)WT * chunks * m.nbuckets > hist_words) hist_words = (size_t)WT * chunks * m.nbuckets;
   }
   G16_HIP(hipMalloc(&ws->d_dig, (dig_words + 4) * 4));
@@ -138,6 +175,7 @@ int msm_workspace_create(MsmWorkspace** out, const MsmInstance* insts, int ninst
   G16_HIP(hipMalloc(&ws->d_sorted, ((size_t)ws->max_entries + 1) * 4));
   G16_HIP(hipMalloc(&ws->d_task_desc, ((size_t)ws->max_tasks + 1) * sizeof(uint2)));
   G16_HIP(hipMalloc(&ws->d_queue, 64));
+  G16_HIP(hipMalloc(&ws->d_redo, ((size_t)ws->max_tasks + 1) * 4));
   G16_HIP(hipMalloc(&ws->d_tile_a, ((size_t)ws->max_buckets / kScanTile + 2) * 4));
   G16_HIP(hipMalloc(&ws->d_tile_b, ((size_t)ws->max_buckets / kScanTile + 2) * 4));
   G16_HIP(hipMalloc(&ws->d_partial, part_bytes + 256));
@@ -156,7 +194,7 @@ int msm_workspace_create(MsmWorkspace** out, const MsmInstance* insts, int ninst
 void msm_workspace_destroy(MsmWorkspace* ws) {
   if (!ws) return;
   void* ptrs[] = {ws->d_cnt, ws->d_off, ws->d_toff, ws->d_sorted, ws->d_task_desc, ws->d_queue, ws->d_tile_a, ws->d_tile_b,
-                  ws->d_partial, ws->d_seg, ws->d_red, ws->d_bsum, ws->d_heavy, ws->d_dig, ws->d_hist, ws->d_canon};
+                  ws->d_partial, ws->d_seg, ws->d_red, ws->d_bsum, ws->d_heavy, ws->d_dig, ws->d_hist, ws->d_canon, ws->d_redo};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   if (ws->h_pinned) (void)hipHostFree(ws->h_pinned);
@@ -168,6 +206,17 @@ void msm_workspace_destroy(MsmWorkspace* ws) {
 int msm_launch_g2(const MsmInstance& m, MsmWorkspace* ws, const Fr* d_scalars, hipStream_t st);
 
 float msm_last_accum_ms(const MsmWorkspace* ws) { return ws->last_accum_ms; }
+void msm_set_schedule(MsmWorkspace* ws, hipEvent_t accum_gate, uint32_t waves_per_simd) {
+  ws->accum_gate = accum_gate;
+  ws->waves_per_simd = waves_per_simd;
+}
+hipEvent_t msm_accum_done_event(MsmWorkspace* ws) { return ws->ev1; }
+float msm_accum_event_offset_ms(MsmWorkspace* ws, hipEvent_t base, int which) {
+  float t = 0.f;
+  hipEvent_t e = which == 0 ? ws->ev0 : which == 1 ? ws->ev1 : ws->trace_ev[which - 2];
+  if (e) (void)hipEventElapsedTime(&t, base, e);
+  return t;
+}
 
 int msm_launch(const MsmInstance& m, MsmWorkspace* ws, const Fr* d_scalars, hipStream_t st) {
   if (m.curve == 2) return msm_launch_g2(m, ws, d_scalars, st);

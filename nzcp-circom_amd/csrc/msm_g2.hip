@@ -13,4 +13,10 @@ int msm_convert_bases_g2(const void* in, void* out, uint32_t n) {
   G16_HIP(hipDeviceSynchronize());
   return G16_OK;
 }
+int msm_precompute_g2(const void* in, void* out, uint32_t n, int ndbl) {
+  msm_precompute_kernel<Fq2Ops><<<(n + 255) / 256, 256>>>((const G2Affine*)in, (G2Affine*)out, n, ndbl);
+  G16_HIP(hipGetLastError());
+  G16_HIP(hipDeviceSynchronize());
+  return G16_OK;
+}
 }  // namespace g16

@@ -511,6 +511,13 @@ static int collect_one_msm(g16_prover* P, ProofCtx& c, int i, XYZZ<F>& out) {
 static int launch_ctx(g16_prover* P, ProofCtx& c, const Fr* d_w) {
   G16_HIP(hipSetDevice(P->device));
   int rc;
+  static const bool trace_host = getenv("G16_TRACE_HOST") != nullptr;
+  const auto th0 = std::chrono::steady_clock::now();
+  auto th = [&](const char* what) {
+    if (trace_host)
+      fprintf(stderr, "[g16 host] %s enqueued at %.3f ms\n", what,
+              std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - th0).count());
+  };
   G16_HIP(hipEventRecord(c.ev[2], c.st));
   // critical chain first (host launch order matters: ~60 witness-MSM launches cost ~0.3 ms of host time)
   if ((rc = qap_eval(P->csr, d_w, c.d_a, c.d_b, c.d_c, c.st))) return rc;
@@ -520,17 +527,34 @@ static int launch_ctx(g16_prover* P, ProofCtx& c, const Fr* d_w) {
   if ((rc = ntt_dit_forward(P->ntt, vecs, 3, c.st))) return rc;
   if ((rc = ntt_join_abc(c.d_a, c.d_b, c.d_c, c.d_p, P->N, c.st))) return rc;
   G16_HIP(hipEventRecord(c.ev[4], c.st));
+  th("qap+ntt");
   static const int order[4] = {2, 3, 0, 1};   // longest chains first: B2 (G2), C, A, B1
+  // experiment knobs: G16_GATE = 5 digits (A,B1,B2,C,H): 1 = that MSM's accumulate waits for the NTT chain;
+  // G16_ACC_WAVES = 5 digits: wavefronts per SIMD of the persistent accumulate grid (0 = full)
+  static const char* gate_s = getenv("G16_GATE");
+  static const char* occ_s = getenv("G16_ACC_WAVES");
+  for (int i = 0; i < 5; i++) {
+    const bool gate = gate_s && strlen(gate_s) == 5 && gate_s[i] == '1';
+    const uint32_t occ = (occ_s && strlen(occ_s) == 5) ? (uint32_t)(occ_s[i] - '0') : 0;
+    msm_set_schedule(c.ws[i], gate ? c.ev[4] : nullptr, occ);
+  }
+  static const bool chain = getenv("G16_CHAIN") != nullptr;
   for (int oi = 0; oi < 4; oi++) {
     const int i = order[oi];
+    if (chain && oi > 0) {   // one witness accumulate at a time: wait for the previously launched one
+      const uint32_t occ = (occ_s && strlen(occ_s) == 5) ? (uint32_t)(occ_s[i] - '0') : 0;
+      msm_set_schedule(c.ws[i], msm_accum_done_event(c.ws[order[oi - 1]]), occ);
+    }
     if (c.mst[i] != c.st) G16_HIP(hipStreamWaitEvent(c.mst[i], c.ev[2], 0));
     G16_HIP(hipEventRecord(c.mev[i][0], c.mst[i]));
     if ((rc = msm_launch(P->msm[i], c.ws[i], d_w, c.mst[i]))) return rc;
     G16_HIP(hipEventRecord(c.mev[i][1], c.mst[i]));
+    th("witness msm");
   }
   G16_HIP(hipEventRecord(c.mev[4][0], c.st));
   if ((rc = msm_launch(P->msm[4], c.ws[4], c.d_p, c.st))) return rc;
   G16_HIP(hipEventRecord(c.mev[4][1], c.st));
+  th("h msm");
   return G16_OK;
 }
 
@@ -553,6 +577,22 @@ static int collect_h_msm(g16_prover* P, ProofCtx& c, Partial& out) {
   (void)hipEventElapsedTime(&c.tm.qap_ms, c.ev[2], c.ev[3]);
   (void)hipEventElapsedTime(&c.tm.ntt_ms, c.ev[3], c.ev[4]);
   (void)hipEventElapsedTime(&c.tm.total_ms, c.ev[2], c.ev[5]);
+  if (getenv("G16_TRACE_HOST")) {
+    static const char* nm[5] = {"A", "B1", "B2", "C", "H"};
+    float t_ntt0 = 0, t_ntt1 = 0;
+    (void)hipEventElapsedTime(&t_ntt0, c.ev[2], c.ev[3]);
+    (void)hipEventElapsedTime(&t_ntt1, c.ev[2], c.ev[4]);
+    fprintf(stderr, "[g16 dev] qap 0..%.3f  ntt+join ..%.3f  total %.3f\n", t_ntt0, t_ntt1, c.tm.total_ms);
+    for (int i = 0; i < 5; i++) {
+      float s0 = 0, s1 = 0;
+      (void)hipEventElapsedTime(&s0, c.ev[2], c.mev[i][0]);
+      (void)hipEventElapsedTime(&s1, c.ev[2], c.mev[i][1]);
+      auto off = [&](int k) { return msm_accum_event_offset_ms(c.ws[i], c.ev[2], k); };
+      fprintf(stderr, "[g16 dev] %-2s start %.3f digits %.3f sort0 %.3f scan %.3f sort1 %.3f | accumulate %.3f..%.3f | "
+              "combine %.3f reduce %.3f tree.. end %.3f\n", nm[i], s0, off(2), off(3), off(4), off(5), off(0), off(1),
+              off(7), off(8), s1);
+    }
+  }
   const float up = P->tm.upload_ms;
   P->tm = c.tm;
   P->tm.upload_ms = up;
