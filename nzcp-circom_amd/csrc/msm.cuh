@@ -357,6 +357,8 @@ __global__ __launch_bounds__(64, F::kAccumWavesPerSimd) void msm_accumulate_kern
   uint2 desc = make_uint2(0, 0);
   XYZZ<F> acc;
   x29_set_inf(acc);
+  // (Staggering the wavefronts of a SIMD by HW_ID.WAVE_ID so that their gathers do not coincide was measured:
+  // no change for G1 -- the kernel is issue-bound, ~5.5 cycles per VALU instruction with 13 % memory wait.)
   for (;;) {
     // 1. lanes whose task is complete write its partial sum
     if (my_task != kNone && cur == end) {
