@@ -107,6 +107,7 @@ float msm_last_accum_ms(const MsmWorkspace* ws);
 // accumulate kernel of the next msm_launch on `ws`: wait for `accum_gate` first (nullptr = none); persistent
 // grid of `waves_per_simd` wavefronts per SIMD (0 = full occupancy)
 void msm_set_schedule(MsmWorkspace* ws, hipEvent_t accum_gate, uint32_t waves_per_simd);
+hipEvent_t msm_sorted_event(MsmWorkspace* ws);       // recorded when the last launch's sorted task list is ready
 hipEvent_t msm_accum_done_event(MsmWorkspace* ws);   // recorded after the accumulate kernel of the last launch
 float msm_accum_event_offset_ms(MsmWorkspace* ws, hipEvent_t base, int which);   // G16_TRACE_HOST timeline
 int msm_run(const MsmInstance& m, MsmWorkspace* ws, const Fr* d_scalars, uint8_t* out_windows,

@@ -24,7 +24,7 @@
 //      wavefront with __shfl_down of the limbs; msm_to_canon_kernel: back to the canonical image.
 //   Window sums (W + 1 points) go back to the host, which does the c*W doublings (internal.h).
 //
-// Roofline note: ~3.4k VALU instructions (1.75k v_mad_u64_u32) per
+// Roofline note: ~2.7k VALU instructions (1.55k v_mad_u64_u32) per
 // gathered point addition, 16 additions per 96 algorithmic bytes: integer-issue bound, not HBM bound.
 #pragma once
 #include <stdlib.h>
@@ -57,6 +57,7 @@ struct MsmWorkspace {
   void* d_canon = nullptr;        // (W+1) canonical XYZZ window sums
   uint8_t* h_pinned = nullptr;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;  // around the bucket-accumulate kernel
+  hipEvent_t ev_sorted = nullptr;           // after the sort + task cut (before the accumulate gate)
   float last_accum_ms = 0.f;
   uint32_t launched_n = 0;
   size_t out_bytes = 0;
@@ -676,6 +677,7 @@ int msm_launch_t(const MsmInstance& m, MsmWorkspace* ws, const Fr* d_scalars, hi
   if (waves > (max_tasks + kTaskChunk - 1) / kTaskChunk) waves = (max_tasks + kTaskChunk - 1) / kTaskChunk;
   if (waves == 0) waves = 1;
   G16_HIP(hipMemsetAsync(ws->d_queue, 0, 8, st));
+  G16_HIP(hipEventRecord(ws->ev_sorted, st));
   if (ws->accum_gate) G16_HIP(hipStreamWaitEvent(st, ws->accum_gate, 0));
   G16_HIP(hipEventRecord(ws->ev0, st));
   msm_accumulate_kernel<F><<<(unsigned)waves, 64, 0, st>>>((const Affine<F>*)m.d_bases, ws->d_sorted, ws->d_toff, nb,

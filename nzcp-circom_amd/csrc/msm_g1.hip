@@ -188,6 +188,7 @@ int msm_workspace_create(MsmWorkspace** out, const MsmInstance* insts, int ninst
   G16_HIP(hipMalloc(&ws->d_canon, pin_bytes + 256));
   G16_HIP(hipEventCreate(&ws->ev0));
   G16_HIP(hipEventCreate(&ws->ev1));
+  G16_HIP(hipEventCreate(&ws->ev_sorted));
   return G16_OK;
 }
 
@@ -200,6 +201,7 @@ void msm_workspace_destroy(MsmWorkspace* ws) {
   if (ws->h_pinned) (void)hipHostFree(ws->h_pinned);
   if (ws->ev0) (void)hipEventDestroy(ws->ev0);
   if (ws->ev1) (void)hipEventDestroy(ws->ev1);
+  if (ws->ev_sorted) (void)hipEventDestroy(ws->ev_sorted);
   delete ws;
 }
 
@@ -211,6 +213,7 @@ void msm_set_schedule(MsmWorkspace* ws, hipEvent_t accum_gate, uint32_t waves_pe
   ws->waves_per_simd = waves_per_simd;
 }
 hipEvent_t msm_accum_done_event(MsmWorkspace* ws) { return ws->ev1; }
+hipEvent_t msm_sorted_event(MsmWorkspace* ws) { return ws->ev_sorted; }
 float msm_accum_event_offset_ms(MsmWorkspace* ws, hipEvent_t base, int which) {
   float t = 0.f;
   hipEvent_t e = which == 0 ? ws->ev0 : which == 1 ? ws->ev1 : ws->trace_ev[which - 2];

@@ -1,0 +1,17 @@
+#!/bin/bash
+# Round profile on the GPU box (run through gpurun from the repo root): default bench line, rocprofv3 kernel
+# stats of the same command, and three PMC passes in serial-MSM mode (one MSM at a time, so a launch's counters
+# are its own).  Outputs under gpurun_out/final/; tools/pmc_summary.py turns them into profiles/*.
+set -e
+OUT=$GRAFT_REPO_ROOT/gpurun_out/final
+rm -rf $OUT && mkdir -p $OUT
+cd $GRAFT_REPO_ROOT
+timeout -k 10 600 python bench.py > $OUT/bench.json 2> $OUT/bench.err
+cd /tmp && export TMPDIR=/tmp
+timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $OUT/prof -o run --output-format csv -- python3 $GRAFT_REPO_ROOT/bench.py --steps 5 --warmup 1 --no-cpu --batch-streams 0 > $OUT/prof_bench.json 2> $OUT/prof.err
+export G16_SERIAL_MSM=1
+timeout -k 10 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/pmc1 -o run --output-format csv -- python3 $GRAFT_REPO_ROOT/bench.py --steps 2 --warmup 1 --no-cpu --batch-streams 0 > /dev/null 2> $OUT/pmc1.err
+timeout -k 10 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum -d $OUT/pmc2 -o run --output-format csv -- python3 $GRAFT_REPO_ROOT/bench.py --steps 2 --warmup 1 --no-cpu --batch-streams 0 > /dev/null 2> $OUT/pmc2.err
+timeout -k 10 300 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_WAVES -d $OUT/pmc3 -o run --output-format csv -- python3 $GRAFT_REPO_ROOT/bench.py --steps 2 --warmup 1 --no-cpu --batch-streams 0 > /dev/null 2> $OUT/pmc3.err
+find $OUT -name "*.csv" | head -20
+tail -c 600 $OUT/bench.json
