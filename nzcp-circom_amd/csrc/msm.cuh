@@ -682,9 +682,9 @@ int msm_launch_t(const MsmInstance& m, MsmWorkspace* ws, const Fr* d_scalars, hi
   G16_HIP(hipEventRecord(ws->ev0, st));
   msm_accumulate_kernel<F><<<(unsigned)waves, 64, 0, st>>>((const Affine<F>*)m.d_bases, ws->d_sorted, ws->d_toff, nb,
                                                             ws->d_task_desc, ws->d_queue, ws->d_redo, (PT*)ws->d_partial);
+  G16_HIP(hipEventRecord(ws->ev1, st));
   msm_redo_kernel<F><<<64, 64, 0, st>>>((const Affine<F>*)m.d_bases, ws->d_sorted, ws->d_task_desc, ws->d_queue,
                                         ws->d_redo, (PT*)ws->d_partial);
-  G16_HIP(hipEventRecord(ws->ev1, st));
   G16_HIP(hipMemsetAsync(ws->d_heavy, 0, 4, st));
   mark(4);
   msm_combine_light_kernel<F><<<(nb + 63) / 64, 64, 0, st>>>((const PT*)ws->d_partial, ws->d_toff, nb,
