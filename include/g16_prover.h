@@ -45,8 +45,10 @@ typedef struct g16_opts {
   int32_t shard_count;  /* base section; 0/1 = whole key                               */
   int32_t window_bits;  /* Pippenger window c (0 = auto)                                           */
   int32_t task_len;     /* max sorted entries per bucket-accumulation task (0 = auto)              */
-  uint32_t flags;       /* reserved, 0 */
+  uint32_t flags;       /* bits 8..15: MSM window-precomputation factor (0 = default, see G16_OPT_PRECOMP); other bits 0 */
 } g16_opts;
+/* flags value asking for a base table with 2^(c*W*k)*P for k < factor (more HBM, fewer bucket rows) */
+#define G16_OPT_PRECOMP(factor) (((uint32_t)(factor) & 0xffu) << 8)
 
 typedef struct g16_proof {
   uint8_t a[64];  /* pi_a: x | y                      */

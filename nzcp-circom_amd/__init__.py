@@ -140,13 +140,13 @@ def stringify(obj):
 class Prover:
     """Resident proving key on one GPU (or one shard of it)."""
 
-    def __init__(self, zkey, device=0, shard_rank=0, shard_count=1, window_bits=0, task_len=0):
+    def __init__(self, zkey, device=0, shard_rank=0, shard_count=1, window_bits=0, task_len=0, precomp=0):
         lib = load()
         if isinstance(zkey, (str, os.PathLike)):
             with open(zkey, "rb") as f:
                 zkey = f.read()
         self._h = C.c_void_p()
-        opts = Opts(device, shard_rank, shard_count, window_bits, task_len, 0)
+        opts = Opts(device, shard_rank, shard_count, window_bits, task_len, (precomp & 0xff) << 8)
         _check(lib.g16_create(zkey, len(zkey), C.byref(opts), C.byref(self._h)))
         self.info = Info()
         _check(lib.g16_get_info(self._h, C.byref(self.info)))

@@ -299,6 +299,7 @@ static int create_impl(const uint8_t* zkey, size_t len, const g16_opts* opts, g1
   MsmConfig cfg;
   cfg.c = opts ? opts->window_bits : 0;
   cfg.task_len = opts ? opts->task_len : 0;
+  cfg.precomp = opts ? (int)((opts->flags >> 8) & 0xffu) : 0;
   const uint32_t totals[5] = {P->nVars, P->nVars, P->nVars, nC, P->N};
   const uint32_t base_off[5] = {0, 0, 0, P->nPublic + 1, 0};
   const int curve[5] = {1, 1, 2, 1, 1};
@@ -710,7 +711,7 @@ int g16_prove_batch(g16_prover* p, const uint8_t* const* wtns, const size_t* wtn
   // proof i is already running on the GPU.
   const size_t wbytes = (size_t)p->nVars * sizeof(Fr);
   Blinding bl[g16_prover::kCtx];
-  int bl_rc[g16_prover::kCtx] = {0, 0};
+  int bl_rc[g16_prover::kCtx] = {};
   auto finish_one = [&](size_t i) -> int {
     ProofCtx& c = p->ctx[i % g16_prover::kCtx];
     if (bl_rc[i % g16_prover::kCtx]) {

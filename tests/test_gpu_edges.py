@@ -71,6 +71,15 @@ def test_every_window_size(amd, c):
     _prove_both(amd, zkb, w, 7, 9, window_bits=c)
 
 
+@pytest.mark.parametrize("pf,c", [(2, 0), (3, 5), (4, 16), (16, 13), (200, 4)])
+def test_window_precomputation(amd, pf, c):
+    """g16_opts.flags = G16_OPT_PRECOMP(pf): base table extended by 2^(c W k) P, scalar windows folded into
+    W = ceil(Ws / pf) bucket rows -- same proof bytes."""
+    zkb, wt, _ = amd.synth_setup(900, 7, 700, 23)
+    w = f.read_wtns(wt)["w"]
+    _prove_both(amd, zkb, w, 7, 9, window_bits=c, precomp=pf)
+
+
 def test_task_len_extremes(amd):
     zkb, wt, _ = amd.synth_setup(700, 513, 100, 22)
     w = f.read_wtns(wt)["w"]

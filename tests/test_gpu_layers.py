@@ -135,6 +135,26 @@ def test_g2_multiexp_known_answer(amd, n, c):
     _msm_case(amd, 2, n, c, random.Random(n * 17 + c))
 
 
+@pytest.mark.parametrize("curve", [1, 2])
+def test_multiexp_exceptional_additions_everywhere(amd, curve):
+    """Every bucket addition is a doubling or a cancellation: the same base 150 times with the same scalar,
+    then its negative 150 times, then 37 more copies.  The accumulate kernel's fast formula cannot add
+    these; its low-limb filter must route every such task to the complete-addition redo pass."""
+    grp = b.G1 if curve == 1 else b.G2
+    enc = f.g1_to_lem if curve == 1 else f.g2_to_lem
+    rng = random.Random(4242 + curve)
+    k = rng.randrange(1, b.R)
+    P = grp.mul(grp.gen, k)
+    s0 = rng.randrange(b.R)
+    bases = [P] * 150 + [grp.neg(P)] * 150 + [P] * 37
+    ks = [k] * 150 + [(-k) % b.R] * 150 + [k] * 37
+    for c in (0, 7, 16):
+        out = amd.multiexp(curve, b"".join(enc(x) for x in bases), _le([s0] * len(bases)), window_bits=c)
+        exp = grp.mul(grp.gen, sum(x * s0 for x in ks) % b.R)
+        want = (f.le(exp[0]) + f.le(exp[1])) if curve == 1 else b"".join(f.le(v) for v in (exp[0][0], exp[0][1], exp[1][0], exp[1][1]))
+        assert out == want
+
+
 def test_multiexp_nzcp_like_scalar_mix(amd):
     """60 % bits / 8 % small / 32 % full-width: one huge bucket + task splitting."""
     rng = random.Random(99)
