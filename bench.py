@@ -186,6 +186,9 @@ def main():
     ap.add_argument("--n-vars", type=int, default=1_700_000)
     ap.add_argument("--n-constraints", type=int, default=1_700_000)
     ap.add_argument("--n-public", type=int, default=513)
+    ap.add_argument("--sha256-blocks", type=int, default=0,
+                    help="BASELINE config 5 on a REAL constraint system: this many chained SHA-256 compressions "
+                         "(163 fill the 2^22 domain) instead of the shape-matched synthetic circuit")
     ap.add_argument("--mode", choices=["shard", "replicas"], default="shard")
     ap.add_argument("--window-bits", type=int, default=0)
     ap.add_argument("--task-len", type=int, default=0)
@@ -226,9 +229,21 @@ def main():
     ncpu = os.cpu_count() or 1
     threads = max(1, ncpu // world)
     t0 = time.time()
-    zkey, wtns, vkey = amd.synth_setup(args.n_vars, args.n_public, args.n_constraints, SEED, threads)
-    log(f"synthetic setup nVars={args.n_vars} nConstraints={args.n_constraints}: {time.time() - t0:.1f}s, "
-        f"zkey {len(zkey) / 1e6:.0f} MB")
+    if args.sha256_blocks > 0:
+        import hashlib
+        out = amd.sha256_chain_setup(args.sha256_blocks, hashlib.sha256(b"nzcp-circom config 5").digest(), SEED, threads)
+        zkey, wtns, vkey = out["zkey"], out["wtns"], out["vkey"]
+        args.n_public = 256
+        args.n_vars = (len(wtns) - 76) // 32
+        args.n_constraints = -1          # read back from the handle below
+        args.batch_streams = 0           # the batch leg draws fresh witnesses from the synthetic generator
+        args.cpu_sample_div = max(args.cpu_sample_div, 1)
+        log(f"sha256-chain setup blocks={args.sha256_blocks} nVars={args.n_vars}: {time.time() - t0:.1f}s, "
+            f"zkey {len(zkey) / 1e6:.0f} MB")
+    else:
+        zkey, wtns, vkey = amd.synth_setup(args.n_vars, args.n_public, args.n_constraints, SEED, threads)
+        log(f"synthetic setup nVars={args.n_vars} nConstraints={args.n_constraints}: {time.time() - t0:.1f}s, "
+            f"zkey {len(zkey) / 1e6:.0f} MB")
     sharded = world > 1 and args.mode == "shard"
     t0 = time.time()
     prover = amd.Prover(zkey, device=dev, shard_rank=rank if sharded else 0,
@@ -343,9 +358,14 @@ def main():
             "n_gpus": world, "steps": K, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / K, 3),
             "higher_is_better": True, "scaling": "strong" if (sharded or world == 1) else "weak",
             "vs_baseline": None, "dtype": "u32x8 (256-bit Montgomery integers)",
-            "data": "synthetic (shape-matched nzcp_live R1CS + trapdoor zkey; real circuit not buildable offline)",
-            "config": {"workload": f"nzcp_live-shaped single proof: nVars={nn}, nConstraints={args.n_constraints}, "
-                                   f"nPublic={info.n_public}, domain=2^{N.bit_length() - 1}, nCoefs={k}",
+            "data": ("real SHA-256-chain constraint system built natively (g16_sha256_chain_setup) + trapdoor zkey"
+                     if args.sha256_blocks > 0 else
+                     "synthetic (shape-matched nzcp_live R1CS + trapdoor zkey; real circuit not buildable offline)"),
+            "config": {"workload": (f"sha256 chain, {args.sha256_blocks} compressions (BASELINE config 5), single proof: "
+                                    f"nVars={nn}, nPublic={info.n_public}, domain=2^{N.bit_length() - 1}, nCoefs={k}"
+                                    if args.sha256_blocks > 0 else
+                                    f"nzcp_live-shaped single proof: nVars={nn}, nConstraints={args.n_constraints}, "
+                                    f"nPublic={info.n_public}, domain=2^{N.bit_length() - 1}, nCoefs={k}"),
                        "parallelism": ("1gpu" if world == 1 else
                                        (f"msm-point-range-shard{world}+allgather" if sharded else f"replicas{world}")),
                        "window_bits": list(info.window_bits)},

@@ -153,6 +153,16 @@ int g16_synth_witness(uint32_t n_vars, uint32_t n_public, uint32_t n_constraints
  * real nzcp_live R1CS and benchmark its true shape; NOT a ceremony -- the trapdoor is known. */
 int g16_r1cs_setup(const uint8_t* r1cs, size_t r1cs_len, uint64_t seed, int threads, uint8_t** zkey,
                    size_t* zkey_len, uint8_t** vkey, size_t* vkey_len);
+
+/* Test-only: a REAL constraint system for BASELINE config 5 -- `blocks` chained SHA-256 compressions
+ * d_{i+1} = SHA-256(d_i) over a 32-byte private message, bit-level R1CS in the style of the circomlib sha256
+ * gadgets nzcptpl.circom includes (/root/reference/circuits/nzcptpl.circom:3-6 include list), ~27 k
+ * constraints per block; public signals = the 256 digest bits, MSB-first (the NZCP circuit's bit order,
+ * /root/reference/test/nzcp.js:41-47).  Trapdoor zkey as g16_synth_setup; r1cs = iden3 .r1cs v1 image.
+ * Any output pair may be NULL. */
+int g16_sha256_chain_setup(uint32_t blocks, const uint8_t msg[32], uint64_t seed, int threads,
+                           uint8_t** zkey, size_t* zkey_len, uint8_t** wtns, size_t* wtns_len,
+                           uint8_t** vkey, size_t* vkey_len, uint8_t** r1cs, size_t* r1cs_len);
 void g16_free(void* p);
 
 #ifdef __cplusplus

@@ -53,7 +53,8 @@ EXPORTS = ["g16_create", "g16_prove", "g16_prove_batch", "g16_stage_witness", "g
            "g16_prove_partial", "g16_prove_finish", "g16_get_info", "g16_get_timings", "g16_destroy",
            "g16_last_error", "g16_fr_fft", "g16_fr_ifft", "g16_fr_batch_mul", "g16_field_op",
            "g16_ec_add", "g16_g1_multiexp", "g16_g2_multiexp", "g16_synth_setup",
-           "g16_synth_witness", "g16_free", "g16_finish_host", "g16_shard_range", "g16_r1cs_setup"]
+           "g16_synth_witness", "g16_free", "g16_finish_host", "g16_shard_range", "g16_r1cs_setup",
+           "g16_sha256_chain_setup"]
 
 
 def load():
@@ -92,6 +93,7 @@ def load():
     lib.g16_synth_witness.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint64, C.c_uint64,
                                       C.POINTER(vp), C.POINTER(sz)]
     lib.g16_r1cs_setup.argtypes = [C.c_char_p, sz, C.c_uint64, C.c_int, C.POINTER(vp), C.POINTER(sz), C.POINTER(vp), C.POINTER(sz)]
+    lib.g16_sha256_chain_setup.argtypes = [C.c_uint32, C.c_char_p, C.c_uint64, C.c_int] + [C.c_void_p] * 8
     lib.g16_finish_host.argtypes = [C.c_char_p, sz, C.c_char_p, C.c_uint32, C.c_char_p, C.c_char_p, C.POINTER(Proof)]
     lib.g16_shard_range.argtypes = [C.c_uint32, C.c_int32, C.c_int32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
     lib.g16_shard_range.restype = None
@@ -257,6 +259,21 @@ def synth_setup(n_vars, n_public, n_constraints, seed, threads=0):
     _check(lib.g16_synth_setup(n_vars, n_public, n_constraints, seed, threads, C.byref(z), C.byref(zl),
                                C.byref(w), C.byref(wl), C.byref(v), C.byref(vl)))
     return _take(z, zl), _take(w, wl), _take(v, vl)
+
+
+def sha256_chain_setup(blocks, msg, seed, threads=0, want_zkey=True, want_r1cs=False):
+    """SHA-256 chain circuit (real constraint system): -> dict(zkey, wtns, vkey, r1cs) of bytes / None."""
+    lib = load()
+    assert len(msg) == 32
+    ptrs = [C.c_void_p() for _ in range(4)]
+    lens = [C.c_size_t() for _ in range(4)]
+    want = [want_zkey, True, want_zkey, want_r1cs]
+    args = []
+    for p_, l_, w_ in zip(ptrs, lens, want):
+        args += [C.byref(p_) if w_ else None, C.byref(l_) if w_ else None]
+    _check(lib.g16_sha256_chain_setup(blocks, msg, seed, threads, *args))
+    out = [(_take(p_, l_) if w_ else None) for p_, l_, w_ in zip(ptrs, lens, want)]
+    return {"zkey": out[0], "wtns": out[1], "vkey": out[2], "r1cs": out[3]}
 
 
 def r1cs_setup(r1cs, seed, threads=0):

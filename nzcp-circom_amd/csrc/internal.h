@@ -63,7 +63,12 @@ struct QapCsr {
   F29* val[2] = {nullptr, nullptr};           // coef * 2^522 (lazy format): one product with the plain witness word
   size_t nnz[2] = {0, 0};
   uint32_t N = 0;
+  // rows with more than kQapLongRow terms in A or B (the modular-addition rows of a SHA-256 circuit carry
+  // ~260): one wavefront each instead of one lane
+  uint32_t* long_rows = nullptr;
+  uint32_t n_long = 0;
 };
+static constexpr uint32_t kQapLongRow = 16;
 // a[c] = sum val*w[col] (lazy Montgomery), b likewise, cc = a*b; w is the standard-form witness
 int qap_eval(const QapCsr& q, const Fr* w_std, F29* a, F29* b, F29* cc, hipStream_t st);
 // zkey section-4 words (device, canonical) -> the lazy coefficient format, once at create

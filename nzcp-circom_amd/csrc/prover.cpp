@@ -160,6 +160,7 @@ struct g16_prover {
       if (csr.col[m]) (void)hipFree(csr.col[m]);
       if (csr.val[m]) (void)hipFree(csr.val[m]);
     }
+    if (csr.long_rows) (void)hipFree(csr.long_rows);
     ntt_tables_destroy(ntt);
     for (auto& m : msm) msm_instance_destroy(m);
   }
@@ -214,6 +215,16 @@ static int build_csr(g16_prover* P, const Section& s4) {
     memcpy(val[m][k].v, rec + 12, 32);
   }
   P->csr.N = N;
+  {
+    std::vector<uint32_t> long_rows;
+    for (uint32_t c = 0; c < N; c++)
+      if (rp[0][c + 1] - rp[0][c] > kQapLongRow || rp[1][c + 1] - rp[1][c] > kQapLongRow) long_rows.push_back(c);
+    P->csr.n_long = (uint32_t)long_rows.size();
+    if (!long_rows.empty()) {
+      G16_HIP(hipMalloc(&P->csr.long_rows, long_rows.size() * 4));
+      G16_HIP(hipMemcpy(P->csr.long_rows, long_rows.data(), long_rows.size() * 4, hipMemcpyHostToDevice));
+    }
+  }
   for (int m = 0; m < 2; m++) {
     const size_t nnz = col[m].size();
     P->csr.nnz[m] = nnz;

@@ -20,6 +20,7 @@ __global__ __launch_bounds__(256) void qap_eval_kernel(
     const Fr* __restrict__ w, F29* __restrict__ a, F29* __restrict__ b, F29* __restrict__ cc, uint32_t N) {
   const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= N) return;
+  if (rpA[c + 1] - rpA[c] > kQapLongRow || rpB[c + 1] - rpB[c] > kQapLongRow) return;   // qap_long_rows_kernel's
   // lazy sums: each term is below 1.1r; weak-reduce every 8 terms so the sum stays below 16r
   F29 sa = f29_zero(), sb = f29_zero();
   uint32_t cnt = 0;
@@ -37,6 +38,46 @@ __global__ __launch_bounds__(256) void qap_eval_kernel(
   cc[c] = fr29_mul(sa, sb);
 }
 
+// One wavefront per long row: lanes stride over the row's records, partial sums meet in a 6-step
+// __shfl_xor tree (weak-reduced on the way so they stay below 16r).
+__device__ __forceinline__ F29 f29_shfl_xor(const F29& v, int mask) {
+  F29 r;
+#pragma unroll
+  for (int i = 0; i < 9; i++) r.l[i] = (uint32_t)__shfl_xor((int)v.l[i], mask, 64);
+  r.pad_ = 0;
+  return r;
+}
+__global__ __launch_bounds__(64) void qap_long_rows_kernel(
+    const uint32_t* __restrict__ rows, uint32_t n_long,
+    const uint32_t* __restrict__ rpA, const uint32_t* __restrict__ colA, const F29* __restrict__ valA,
+    const uint32_t* __restrict__ rpB, const uint32_t* __restrict__ colB, const F29* __restrict__ valB,
+    const Fr* __restrict__ w, F29* __restrict__ a, F29* __restrict__ b, F29* __restrict__ cc) {
+  if (blockIdx.x >= n_long) return;
+  const uint32_t c = rows[blockIdx.x], lane = threadIdx.x;
+  F29 s[2] = {f29_zero(), f29_zero()};
+#pragma unroll
+  for (int m = 0; m < 2; m++) {
+    const uint32_t* rp = m ? rpB : rpA;
+    const uint32_t* col = m ? colB : colA;
+    const F29* val = m ? valB : valA;
+    uint32_t cnt = 0;
+    for (uint32_t k = rp[c] + lane, e = rp[c + 1]; k < e; k += 64) {
+      s[m] = fr29_add(s[m], fr29_mul(val[k], fr29_repack(w[col[k]])));
+      if ((++cnt & 7u) == 0) s[m] = fr29_weak_reduce(s[m]);
+    }
+    s[m] = fr29_weak_reduce(s[m]);
+    for (int d = 32; d >= 1; d >>= 1) {
+      s[m] = fr29_add(s[m], f29_shfl_xor(s[m], d));
+      if (d == 8 || d == 1) s[m] = fr29_weak_reduce(s[m]);   // at most 8 partials below ~2r between reductions
+    }
+  }
+  if (lane == 0) {
+    a[c] = s[0];
+    b[c] = s[1];
+    cc[c] = fr29_mul(s[0], s[1]);
+  }
+}
+
 __global__ __launch_bounds__(256) void qap_convert_kernel(const Fr* __restrict__ in, F29* __restrict__ out, size_t n) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) out[i] = fr29_from_zkey_coef(in[i]);
@@ -45,6 +86,9 @@ __global__ __launch_bounds__(256) void qap_convert_kernel(const Fr* __restrict__
 int qap_eval(const QapCsr& q, const Fr* w_std, F29* a, F29* b, F29* cc, hipStream_t st) {
   qap_eval_kernel<<<(q.N + 255) / 256, 256, 0, st>>>(q.row_ptr[0], q.col[0], q.val[0], q.row_ptr[1],
                                                       q.col[1], q.val[1], w_std, a, b, cc, q.N);
+  if (q.n_long)
+    qap_long_rows_kernel<<<q.n_long, 64, 0, st>>>(q.long_rows, q.n_long, q.row_ptr[0], q.col[0], q.val[0], q.row_ptr[1],
+                                                  q.col[1], q.val[1], w_std, a, b, cc);
   G16_HIP(hipGetLastError());
   return G16_OK;
 }

@@ -10,6 +10,8 @@
 // two produce byte-identical zkey/wtns for the same seed.  The arithmetic is the product's own
 // fp.cuh / ec.cuh compiled for the host.
 #include <stdlib.h>
+#include <algorithm>
+#include <array>
 #include <string.h>
 
 #include <thread>
@@ -523,6 +525,252 @@ extern "C" int g16_synth_setup(uint32_t n, uint32_t p, uint32_t m, uint64_t seed
     *wtns = b.p;
     *wtns_len = b.len;
   }
+  return G16_OK;
+}
+
+// ------------------------------------------------------------------ SHA-256 chain circuit
+// A REAL constraint system instead of the shape-matched random one: `blocks` chained SHA-256 compressions,
+//   d_0 = the 32-byte private message,  d_{i+1} = SHA-256(d_i)   (one padded 64-byte block each),
+// public outputs = the 256 bits of d_blocks, MSB-first per byte -- the bit order of the NZCP circuit's
+// sha256 outputs (/root/reference/test/nzcp.js:41-47).  Bit-level R1CS in the style of circomlib's sha256
+// gadgets that nzcptpl.circom includes (xor3 / ch / maj as one or two products per bit, modular additions as
+// one linear row plus a booleanity row per result and carry bit): ~27 k constraints per block, 155 blocks
+// fill a 2^22 domain.  Every wire is a bit, so the witness is bits only.
+namespace g16 {
+namespace {
+
+struct Lin { std::vector<std::pair<uint32_t, int64_t>> t; };   // sum of coef * wire (wire 0 = the constant 1)
+struct Bit { int32_t wire; int8_t a, b; };                     // value = a * w[wire] + b,  a in {0, 1, -1}
+inline Bit bit_const(int v) { return Bit{0, 0, (int8_t)v}; }
+inline Bit bit_wire(uint32_t w) { return Bit{(int32_t)w, 1, 0}; }
+inline Bit bit_not(const Bit& x) { return Bit{x.wire, (int8_t)-x.a, (int8_t)(1 - x.b)}; }
+inline bool bit_is_const(const Bit& x) { return x.a == 0; }
+
+struct ShaBuilder {
+  std::vector<uint8_t> w;        // witness: one bit per wire
+  Circuit c;
+  FrM pow2[40];                  // 2^k in Montgomery form, and small-coefficient cache
+  ShaBuilder() {
+    w.push_back(1);              // wire 0
+    c.rowA.assign(1, 0); c.rowB.assign(1, 0); c.rowC.assign(1, 0);
+  }
+  int val(const Bit& x) const { return x.a * (int)w[x.wire] + x.b; }
+  uint32_t new_wire(int v) { w.push_back((uint8_t)v); return (uint32_t)w.size() - 1; }
+  static FrM coef_of(int64_t v) { return v >= 0 ? fr_u64((uint64_t)v) : fp_neg(fr_u64((uint64_t)(-v))); }
+  static void add(Lin& l, const Bit& x, int64_t mul) {
+    if (x.a) l.t.push_back({(uint32_t)x.wire, mul * x.a});
+    if (x.b) l.t.push_back({0u, mul * x.b});
+  }
+  void push(std::vector<Term>& dst, std::vector<uint32_t>& rows, Lin& l) {
+    // merge duplicate wires (the constant wire shows up several times), drop zeros
+    std::sort(l.t.begin(), l.t.end());
+    size_t i = 0;
+    while (i < l.t.size()) {
+      int64_t sum = 0;
+      const uint32_t wire = l.t[i].first;
+      while (i < l.t.size() && l.t[i].first == wire) sum += l.t[i++].second;
+      if (sum) dst.push_back({wire, coef_of(sum)});
+    }
+    rows.push_back((uint32_t)dst.size());
+  }
+  void constrain(Lin a, Lin b, Lin cc) {   // <a,w> * <b,w> = <cc,w>
+    push(c.tA, c.rowA, a); push(c.tB, c.rowB, b); push(c.tC, c.rowC, cc);
+  }
+  void boolean(uint32_t wire) {   // b * (b - 1) = 0
+    Lin a, b, z;
+    a.t.push_back({wire, 1});
+    b.t.push_back({wire, 1}); b.t.push_back({0u, -1});
+    constrain(a, b, z);
+  }
+  Bit xor2(const Bit& x, const Bit& y) {
+    if (bit_is_const(x)) return x.b ? bit_not(y) : y;
+    if (bit_is_const(y)) return y.b ? bit_not(x) : x;
+    const uint32_t z = new_wire(val(x) ^ val(y));
+    Lin a, b, cc;                 // (2x) * y = x + y - z
+    add(a, x, 2); add(b, y, 1); add(cc, x, 1); add(cc, y, 1); cc.t.push_back({z, -1});
+    constrain(a, b, cc);
+    return bit_wire(z);
+  }
+  Bit xor3(const Bit& x, const Bit& y, const Bit& z) { return xor2(xor2(x, y), z); }
+  Bit ch(const Bit& e, const Bit& f, const Bit& g) {   // e ? f : g  =  g + e (f - g)
+    const uint32_t o = new_wire(val(e) ? val(f) : val(g));
+    Lin a, b, cc;
+    add(a, e, 1); add(b, f, 1); add(b, g, -1); cc.t.push_back({o, 1}); add(cc, g, -1);
+    constrain(a, b, cc);
+    return bit_wire(o);
+  }
+  Bit maj(const Bit& x, const Bit& y, const Bit& z) {  // mid = x y ; out = mid + z (x + y - 2 mid)
+    const uint32_t mid = new_wire(val(x) & val(y));
+    {
+      Lin a, b, cc;
+      add(a, x, 1); add(b, y, 1); cc.t.push_back({mid, 1});
+      constrain(a, b, cc);
+    }
+    const int vx = val(x), vy = val(y), vz = val(z);
+    const uint32_t o = new_wire((vx & vy) | (vx & vz) | (vy & vz));
+    Lin a, b, cc;
+    add(a, z, 1); add(b, x, 1); add(b, y, 1); b.t.push_back({mid, -2}); cc.t.push_back({o, 1}); cc.t.push_back({mid, -1});
+    constrain(a, b, cc);
+    return bit_wire(o);
+  }
+  using Word = std::array<Bit, 32>;   // bit i has weight 2^i
+  static Word word_const(uint32_t v) {
+    Word r;
+    for (int i = 0; i < 32; i++) r[i] = bit_const((v >> i) & 1);
+    return r;
+  }
+  static Word rotr(const Word& x, int k) { Word r; for (int i = 0; i < 32; i++) r[i] = x[(i + k) & 31]; return r; }
+  static Word shr(const Word& x, int k) { Word r; for (int i = 0; i < 32; i++) r[i] = i + k < 32 ? x[i + k] : bit_const(0); return r; }
+  Word xor3w(const Word& a, const Word& b, const Word& d) { Word r; for (int i = 0; i < 32; i++) r[i] = xor3(a[i], b[i], d[i]); return r; }
+  uint32_t word_val(const Word& x) const { uint32_t v = 0; for (int i = 0; i < 32; i++) v |= (uint32_t)val(x[i]) << i; return v; }
+  // sum of the operands mod 2^32: result bits (fresh wires, or `out_wires` when given) and carry bits are
+  // constrained boolean; one linear row ties them to the operands
+  Word add_mod32(const std::vector<Word>& ops, const uint32_t* out_wires = nullptr) {
+    uint64_t sum = 0;
+    for (const Word& o : ops) sum += word_val(o);
+    int ncarry = 0;
+    while (((uint64_t)ops.size() << 32) > ((uint64_t)1 << (32 + ncarry))) ncarry++;
+    Lin a, b, z;
+    for (const Word& o : ops)
+      for (int i = 0; i < 32; i++) add(a, o[i], (int64_t)1 << i);
+    Word r;
+    for (int i = 0; i < 32 + ncarry; i++) {
+      const int v = (int)((sum >> i) & 1);
+      uint32_t wire;
+      if (i < 32 && out_wires) { wire = out_wires[i]; w[wire] = (uint8_t)v; }
+      else wire = new_wire(v);
+      boolean(wire);
+      a.t.push_back({wire, -((int64_t)1 << i)});
+      if (i < 32) r[i] = bit_wire(wire);
+    }
+    b.t.push_back({0u, 1});
+    constrain(a, b, z);
+    return r;
+  }
+};
+
+const uint32_t kShaK[64] = {
+    0x428a2f98, 0x71374491, 0xb5c0fbcf, 0xe9b5dba5, 0x3956c25b, 0x59f111f1, 0x923f82a4, 0xab1c5ed5, 0xd807aa98, 0x12835b01,
+    0x243185be, 0x550c7dc3, 0x72be5d74, 0x80deb1fe, 0x9bdc06a7, 0xc19bf174, 0xe49b69c1, 0xefbe4786, 0x0fc19dc6, 0x240ca1cc,
+    0x2de92c6f, 0x4a7484aa, 0x5cb0a9dc, 0x76f988da, 0x983e5152, 0xa831c66d, 0xb00327c8, 0xbf597fc7, 0xc6e00bf3, 0xd5a79147,
+    0x06ca6351, 0x14292967, 0x27b70a85, 0x2e1b2138, 0x4d2c6dfc, 0x53380d13, 0x650a7354, 0x766a0abb, 0x81c2c92e, 0x92722c85,
+    0xa2bfe8a1, 0xa81a664b, 0xc24b8b70, 0xc76c51a3, 0xd192e819, 0xd6990624, 0xf40e3585, 0x106aa070, 0x19a4c116, 0x1e376c08,
+    0x2748774c, 0x34b0bcb5, 0x391c0cb3, 0x4ed8aa4a, 0x5b9cca4f, 0x682e6ff3, 0x748f82ee, 0x78a5636f, 0x84c87814, 0x8cc70208,
+    0x90befffa, 0xa4506ceb, 0xbef9a3f7, 0xc67178f2};
+const uint32_t kShaIV[8] = {0x6a09e667, 0xbb67ae85, 0x3c6ef372, 0xa54ff53a, 0x510e527f, 0x9b05688c, 0x1f83d9ab, 0x5be0cd19};
+
+// wires: 0 = one, 1..256 = public outputs (digest bits, MSB-first), 257..512 = private message bits, then gates
+void build_sha256_chain(ShaBuilder& sb, uint32_t blocks, const uint8_t msg[32]) {
+  using Word = ShaBuilder::Word;
+  for (int i = 0; i < 256; i++) sb.new_wire(0);   // outputs, values filled by the last addition
+  Word m[8];
+  for (int j = 0; j < 8; j++)
+    for (int k = 0; k < 32; k++) {   // message bit 32 j + k (MSB-first) = bit 31 - k of big-endian word j
+      const int v = (msg[4 * j + k / 8] >> (7 - (k & 7))) & 1;
+      const uint32_t wire = sb.new_wire(v);
+      sb.boolean(wire);
+      m[j][31 - k] = bit_wire(wire);
+    }
+  for (uint32_t blk = 0; blk < blocks; blk++) {
+    Word W[64];
+    for (int j = 0; j < 8; j++) W[j] = m[j];
+    W[8] = ShaBuilder::word_const(0x80000000u);
+    for (int j = 9; j < 15; j++) W[j] = ShaBuilder::word_const(0);
+    W[15] = ShaBuilder::word_const(256);
+    for (int t = 16; t < 64; t++) {
+      const Word s0 = sb.xor3w(ShaBuilder::rotr(W[t - 15], 7), ShaBuilder::rotr(W[t - 15], 18), ShaBuilder::shr(W[t - 15], 3));
+      const Word s1 = sb.xor3w(ShaBuilder::rotr(W[t - 2], 17), ShaBuilder::rotr(W[t - 2], 19), ShaBuilder::shr(W[t - 2], 10));
+      W[t] = sb.add_mod32({W[t - 16], s0, W[t - 7], s1});
+    }
+    Word st[8];
+    for (int j = 0; j < 8; j++) st[j] = ShaBuilder::word_const(kShaIV[j]);
+    Word a = st[0], b = st[1], c = st[2], d = st[3], e = st[4], f = st[5], g = st[6], h = st[7];
+    for (int t = 0; t < 64; t++) {
+      const Word S1 = sb.xor3w(ShaBuilder::rotr(e, 6), ShaBuilder::rotr(e, 11), ShaBuilder::rotr(e, 25));
+      Word chw, mjw;
+      for (int i = 0; i < 32; i++) chw[i] = bit_is_const(e[i]) ? (e[i].b ? f[i] : g[i]) : sb.ch(e[i], f[i], g[i]);
+      const Word S0 = sb.xor3w(ShaBuilder::rotr(a, 2), ShaBuilder::rotr(a, 13), ShaBuilder::rotr(a, 22));
+      for (int i = 0; i < 32; i++) {
+        if (bit_is_const(a[i]) && bit_is_const(b[i]) && bit_is_const(c[i]))
+          mjw[i] = bit_const((a[i].b & b[i].b) | (a[i].b & c[i].b) | (b[i].b & c[i].b));
+        else
+          mjw[i] = sb.maj(a[i], b[i], c[i]);
+      }
+      const Word kw = ShaBuilder::word_const(kShaK[t]);
+      const Word ne = sb.add_mod32({d, h, S1, chw, kw, W[t]});
+      const Word na = sb.add_mod32({h, S1, chw, kw, W[t], S0, mjw});
+      h = g; g = f; f = e; e = ne; d = c; c = b; b = a; a = na;
+    }
+    const Word fin[8] = {a, b, c, d, e, f, g, h};
+    for (int j = 0; j < 8; j++) {
+      if (blk + 1 == blocks) {
+        uint32_t outw[32];   // result bit i (weight 2^i) of word j is output bit 32 j + (31 - i)
+        for (int i = 0; i < 32; i++) outw[i] = 1 + 32 * j + (31 - i);
+        m[j] = sb.add_mod32({st[j], fin[j]}, outw);
+      } else {
+        m[j] = sb.add_mod32({st[j], fin[j]});
+      }
+    }
+  }
+  sb.c.n = (uint32_t)sb.w.size();
+  sb.c.p = 256;
+  sb.c.m = (uint32_t)sb.c.rowA.size() - 1;
+}
+
+void write_r1cs(const Circuit& c, uint32_t n_pub_out, uint32_t n_pub_in, Buf& b) {
+  const size_t nnz = c.tA.size() + c.tB.size() + c.tC.size();
+  const size_t s1 = 4 + 32 + 16 + 8 + 4, s2 = (size_t)c.m * 12 + nnz * 36, s3 = (size_t)c.n * 8;
+  b.reserve(12 + 3 * 12 + s1 + s2 + s3);
+  b.put("r1cs", 4); b.u32(1); b.u32(3);
+  static const uint32_t R[8] = G16_FR_P;
+  b.u32(1); b.u64(s1);
+  b.u32(32); b.put(R, 32); b.u32(c.n); b.u32(n_pub_out); b.u32(n_pub_in); b.u32(c.n - 1 - n_pub_out - n_pub_in);
+  b.u64(c.n); b.u32(c.m);
+  b.u32(2); b.u64(s2);
+  const std::vector<Term>* ts[3] = {&c.tA, &c.tB, &c.tC};
+  const std::vector<uint32_t>* rs[3] = {&c.rowA, &c.rowB, &c.rowC};
+  for (uint32_t r = 0; r < c.m; r++)
+    for (int k = 0; k < 3; k++) {
+      const uint32_t lo = (*rs[k])[r], hi = (*rs[k])[r + 1];
+      b.u32(hi - lo);
+      for (uint32_t t = lo; t < hi; t++) {
+        b.u32((*ts[k])[t].s);
+        const Fr plain = fp_from_mont((*ts[k])[t].cf);
+        b.put(plain.v, 32);
+      }
+    }
+  b.u32(3); b.u64(s3);
+  for (uint32_t i = 0; i < c.n; i++) b.u64(i);
+}
+
+}  // namespace
+}  // namespace g16
+
+// Test-only: the SHA-256 chain circuit above, keyed with a known trapdoor.  Any output pointer may be
+// NULL.  r1cs: iden3 .r1cs v1 image of the same constraint system (for snarkjs / tools/r1cs_setup.py).
+extern "C" int g16_sha256_chain_setup(uint32_t blocks, const uint8_t msg[32], uint64_t seed, int threads,
+                                      uint8_t** zkey, size_t* zkey_len, uint8_t** wtns, size_t* wtns_len,
+                                      uint8_t** vkey, size_t* vkey_len, uint8_t** r1cs, size_t* r1cs_len) {
+  if (!msg || blocks == 0 || blocks > 4096) { set_error("sha256 chain: bad arguments"); return G16_E_ARG; }
+  ShaBuilder sb;
+  build_sha256_chain(sb, blocks, msg);
+  if ((uint64_t)sb.c.m + sb.c.p + 1 > ((uint64_t)1 << 27)) { set_error("sha256 chain: circuit too large"); return G16_E_ARG; }
+  if (wtns && wtns_len) {
+    std::vector<FrM> w(sb.w.size());
+    const FrM one = fr_one(), zero = fp_zero<FrParams>();
+    for (size_t i = 0; i < w.size(); i++) w[i] = sb.w[i] ? one : zero;
+    Buf b;
+    write_wtns(w, b);
+    *wtns = b.p;
+    *wtns_len = b.len;
+  }
+  if (r1cs && r1cs_len) {
+    Buf b;
+    write_r1cs(sb.c, 256, 0, b);
+    *r1cs = b.p;
+    *r1cs_len = b.len;
+  }
+  if (zkey && zkey_len) return setup_core(sb.c, seed, threads, zkey, zkey_len, vkey, vkey_len);
   return G16_OK;
 }
 

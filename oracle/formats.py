@@ -101,6 +101,32 @@ def write_r1cs(n_wires, n_pub_out, n_pub_in, rows):
     return write_binfile("r1cs", 1, [(1, hdr), (2, b"".join(body)), (3, wmap)])
 
 
+def read_r1cs(buf, name="r1cs"):
+    """-> dict(nWires, nPubOut, nPubIn, nPrvIn, rows=[(A, B, C)] with terms [(wire, coef)])."""
+    secs = read_binfile(buf, "r1cs", 1, name)
+    h = section(buf, secs, 1)
+    n8 = struct.unpack_from("<I", h, 0)[0]
+    prime = from_le(h[4:4 + n8])
+    nw, npo, npi, nprv = struct.unpack_from("<IIII", h, 4 + n8)
+    ncons = struct.unpack_from("<I", h, 4 + n8 + 16 + 8)[0]
+    body = section(buf, secs, 2)
+    pos = 0
+    rows = []
+    for _ in range(ncons):
+        row = []
+        for _k in range(3):
+            nt = struct.unpack_from("<I", body, pos)[0]
+            pos += 4
+            lc = []
+            for _t in range(nt):
+                wire = struct.unpack_from("<I", body, pos)[0]
+                lc.append((wire, from_le(body[pos + 4:pos + 4 + n8])))
+                pos += 4 + n8
+            row.append(lc)
+        rows.append(tuple(row))
+    return {"n8": n8, "prime": prime, "nWires": nw, "nPubOut": npo, "nPubIn": npi, "nPrvIn": nprv, "rows": rows}
+
+
 # ------------------------------------------------------------------ .wtns (App. A.2)
 def write_wtns(witness):
     hdr = struct.pack("<I", N8) + le(R) + struct.pack("<I", len(witness))

@@ -124,6 +124,42 @@ def test_config3_batch_throughput_mode(amd):
     prover.close()
 
 
+def _bits_msb_first(data):
+    return [str((byte >> (7 - k)) & 1) for byte in data for k in range(8)]
+
+
+@pytest.mark.parametrize("blocks", [2, 163])
+def test_config5_sha256_chain_real_circuit(amd, blocks):
+    """config 5 with a REAL constraint system: `blocks` chained SHA-256 compressions (163 fill the 2^22 domain),
+    witness of bits only.  public.json must be the digest bits hashlib computes; the proof must verify; at the
+    small size it must also equal the C oracle's bytes."""
+    msg = hashlib.sha256(b"nzcp-circom config 5").digest()
+    seed = synth.SEED_NZCP + 50 + blocks
+    out = amd.sha256_chain_setup(blocks, msg, seed)
+    zkey, wtns, vk = out["zkey"], out["wtns"], _vk(out["vkey"], 256)
+    d = msg
+    for _ in range(blocks):
+        d = hashlib.sha256(d).digest()
+    r, s = _rs(seed)
+    prover = amd.Prover(zkey)
+    assert prover.info.n_public == 256
+    assert prover.info.domain_size == (1 << 22 if blocks == 163 else 1 << 16)
+    proof, pub = prover.prove(wtns, f.le(r), f.le(s))
+    assert pub == _bits_msb_first(d)
+    assert g.verify(vk, [int(x) for x in pub], _points(proof))
+    if blocks == 2:
+        olib = _oracle_c()
+        obuf = ctypes.create_string_buffer(256)
+        opub = ctypes.create_string_buffer(256 * 32)
+        assert olib.g16o_prove(zkey, len(zkey), wtns, len(wtns), f.le(r), f.le(s), obuf, opub, os.cpu_count() or 1) == 0
+        pr = amd.Proof()
+        gpub = ctypes.create_string_buffer(256 * 32)
+        prover.stage(0, wtns)
+        assert prover.prove_staged_raw(0, f.le(r), f.le(s), pr, gpub) == 0
+        assert bytes(pr.a) + bytes(pr.b) + bytes(pr.c) == obuf.raw and gpub.raw == opub.raw
+    prover.close()
+
+
 def test_config5_stress_2_22(amd):
     """config 5: N = 2^22 (n = nConstraints = 2^22 - 514), the largest configuration in BASELINE.json."""
     n = (1 << 22) - (P_NZCP + 1)
