@@ -163,6 +163,25 @@ int g16_r1cs_setup(const uint8_t* r1cs, size_t r1cs_len, uint64_t seed, int thre
 int g16_sha256_chain_setup(uint32_t blocks, const uint8_t msg[32], uint64_t seed, int threads,
                            uint8_t** zkey, size_t* zkey_len, uint8_t** wtns, size_t* wtns_len,
                            uint8_t** vkey, size_t* vkey_len, uint8_t** r1cs, size_t* r1cs_len);
+
+/* Test-only: plain SHA-256 of a `len`-byte private message (len fixed at circuit-build time, FIPS 180-4
+ * padding, multi-block), same gadgets and wire layout: public signals = the 256 digest bits MSB-first, i.e.
+ * the `toBeSignedSha256` slice of the NZCP circuit's public.json when msg = the pass's ToBeSigned
+ * (/root/reference/circuits/nzcptpl.circom:447-500, /root/reference/test/nzcp.js:41-47). */
+int g16_sha256_message_setup(const uint8_t* msg, uint32_t len, uint64_t seed, int threads,
+                             uint8_t** zkey, size_t* zkey_len, uint8_t** wtns, size_t* wtns_len,
+                             uint8_t** vkey, size_t* vkey_len, uint8_t** r1cs, size_t* r1cs_len);
+
+/* Test-only: the NZCP circuit's public interface on a FIXED pass layout -- public signals [0..255] =
+ * SHA-256("given,family,dob") bits, [256..511] = SHA-256(ToBeSigned) bits, [512] = exp, exactly the layout and
+ * bit order of /root/reference/test/nzcp.js:41-47 -- with the byte offsets of the three strings and of the
+ * 4 exp bytes inside ToBeSigned given as circuit constants (the reference finds them by in-circuit CBOR parsing,
+ * /root/reference/circuits/cbortpl.circom; not restated).  The credential string reuses the ToBeSigned bit
+ * wires, so the three outputs are bound to one ToBeSigned. */
+int g16_nzcp_fixed_layout_setup(const uint8_t* tbs, uint32_t len, const uint32_t seg_off[3], const uint32_t seg_len[3],
+                                uint32_t exp_off, uint64_t seed, int threads,
+                                uint8_t** zkey, size_t* zkey_len, uint8_t** wtns, size_t* wtns_len,
+                                uint8_t** vkey, size_t* vkey_len, uint8_t** r1cs, size_t* r1cs_len);
 void g16_free(void* p);
 
 #ifdef __cplusplus

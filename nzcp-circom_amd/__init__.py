@@ -54,7 +54,7 @@ EXPORTS = ["g16_create", "g16_prove", "g16_prove_batch", "g16_stage_witness", "g
            "g16_last_error", "g16_fr_fft", "g16_fr_ifft", "g16_fr_batch_mul", "g16_field_op",
            "g16_ec_add", "g16_g1_multiexp", "g16_g2_multiexp", "g16_synth_setup",
            "g16_synth_witness", "g16_free", "g16_finish_host", "g16_shard_range", "g16_r1cs_setup",
-           "g16_sha256_chain_setup"]
+           "g16_sha256_chain_setup", "g16_sha256_message_setup", "g16_nzcp_fixed_layout_setup"]
 
 
 def load():
@@ -94,6 +94,9 @@ def load():
                                       C.POINTER(vp), C.POINTER(sz)]
     lib.g16_r1cs_setup.argtypes = [C.c_char_p, sz, C.c_uint64, C.c_int, C.POINTER(vp), C.POINTER(sz), C.POINTER(vp), C.POINTER(sz)]
     lib.g16_sha256_chain_setup.argtypes = [C.c_uint32, C.c_char_p, C.c_uint64, C.c_int] + [C.c_void_p] * 8
+    lib.g16_sha256_message_setup.argtypes = [C.c_char_p, C.c_uint32, C.c_uint64, C.c_int] + [C.c_void_p] * 8
+    lib.g16_nzcp_fixed_layout_setup.argtypes = [C.c_char_p, C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32),
+                                                C.c_uint32, C.c_uint64, C.c_int] + [C.c_void_p] * 8
     lib.g16_finish_host.argtypes = [C.c_char_p, sz, C.c_char_p, C.c_uint32, C.c_char_p, C.c_char_p, C.POINTER(Proof)]
     lib.g16_shard_range.argtypes = [C.c_uint32, C.c_int32, C.c_int32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
     lib.g16_shard_range.restype = None
@@ -261,19 +264,44 @@ def synth_setup(n_vars, n_public, n_constraints, seed, threads=0):
     return _take(z, zl), _take(w, wl), _take(v, vl)
 
 
-def sha256_chain_setup(blocks, msg, seed, threads=0, want_zkey=True, want_r1cs=False):
-    """SHA-256 chain circuit (real constraint system): -> dict(zkey, wtns, vkey, r1cs) of bytes / None."""
+def sha256_chain_setup(blocks, msg, seed, threads=0, want_zkey=True, want_r1cs=False, chain=True):
+    """SHA-256 chain circuit (chain=True: `blocks` compressions over a 32-byte message) or plain SHA-256 of `msg`
+    (chain=False): a real constraint system -> dict(zkey, wtns, vkey, r1cs) of bytes / None."""
     lib = load()
-    assert len(msg) == 32
+    assert not chain or len(msg) == 32
     ptrs = [C.c_void_p() for _ in range(4)]
     lens = [C.c_size_t() for _ in range(4)]
     want = [want_zkey, True, want_zkey, want_r1cs]
     args = []
     for p_, l_, w_ in zip(ptrs, lens, want):
         args += [C.byref(p_) if w_ else None, C.byref(l_) if w_ else None]
-    _check(lib.g16_sha256_chain_setup(blocks, msg, seed, threads, *args))
+    if chain:
+        _check(lib.g16_sha256_chain_setup(blocks, msg, seed, threads, *args))
+    else:
+        _check(lib.g16_sha256_message_setup(msg, len(msg), seed, threads, *args))
     out = [(_take(p_, l_) if w_ else None) for p_, l_, w_ in zip(ptrs, lens, want)]
     return {"zkey": out[0], "wtns": out[1], "vkey": out[2], "r1cs": out[3]}
+
+
+def nzcp_fixed_layout_setup(tbs, segs, exp_off, seed, threads=0, want_zkey=True, want_r1cs=False):
+    """The NZCP public interface on a fixed pass layout: segs = [(offset, length)] x 3 of givenName, familyName,
+    dob inside ToBeSigned; exp_off = offset of the 4 big-endian exp bytes.  -> dict(zkey, wtns, vkey, r1cs)."""
+    lib = load()
+    ptrs = [C.c_void_p() for _ in range(4)]
+    lens = [C.c_size_t() for _ in range(4)]
+    want = [want_zkey, True, want_zkey, want_r1cs]
+    args = []
+    for p_, l_, w_ in zip(ptrs, lens, want):
+        args += [C.byref(p_) if w_ else None, C.byref(l_) if w_ else None]
+    off = (C.c_uint32 * 3)(*[o for o, _ in segs])
+    ln = (C.c_uint32 * 3)(*[n for _, n in segs])
+    _check(lib.g16_nzcp_fixed_layout_setup(tbs, len(tbs), off, ln, exp_off, seed, threads, *args))
+    out = [(_take(p_, l_) if w_ else None) for p_, l_, w_ in zip(ptrs, lens, want)]
+    return {"zkey": out[0], "wtns": out[1], "vkey": out[2], "r1cs": out[3]}
+
+
+def sha256_message_setup(msg, seed, threads=0, want_zkey=True, want_r1cs=False):
+    return sha256_chain_setup(0, msg, seed, threads, want_zkey, want_r1cs, chain=False)
 
 
 def r1cs_setup(r1cs, seed, threads=0):

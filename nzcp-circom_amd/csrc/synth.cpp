@@ -547,7 +547,7 @@ inline Bit bit_not(const Bit& x) { return Bit{x.wire, (int8_t)-x.a, (int8_t)(1 -
 inline bool bit_is_const(const Bit& x) { return x.a == 0; }
 
 struct ShaBuilder {
-  std::vector<uint8_t> w;        // witness: one bit per wire
+  std::vector<uint64_t> w;       // witness: one bit per wire (the NZCP circuit's `exp` output is the one wider value)
   Circuit c;
   FrM pow2[40];                  // 2^k in Montgomery form, and small-coefficient cache
   ShaBuilder() {
@@ -555,7 +555,7 @@ struct ShaBuilder {
     c.rowA.assign(1, 0); c.rowB.assign(1, 0); c.rowC.assign(1, 0);
   }
   int val(const Bit& x) const { return x.a * (int)w[x.wire] + x.b; }
-  uint32_t new_wire(int v) { w.push_back((uint8_t)v); return (uint32_t)w.size() - 1; }
+  uint32_t new_wire(uint64_t v) { w.push_back(v); return (uint32_t)w.size() - 1; }
   static FrM coef_of(int64_t v) { return v >= 0 ? fr_u64((uint64_t)v) : fp_neg(fr_u64((uint64_t)(-v))); }
   static void add(Lin& l, const Bit& x, int64_t mul) {
     if (x.a) l.t.push_back({(uint32_t)x.wire, mul * x.a});
@@ -637,7 +637,7 @@ struct ShaBuilder {
     for (int i = 0; i < 32 + ncarry; i++) {
       const int v = (int)((sum >> i) & 1);
       uint32_t wire;
-      if (i < 32 && out_wires) { wire = out_wires[i]; w[wire] = (uint8_t)v; }
+      if (i < 32 && out_wires) { wire = out_wires[i]; w[wire] = (uint64_t)v; }
       else wire = new_wire(v);
       boolean(wire);
       a.t.push_back({wire, -((int64_t)1 << i)});
@@ -659,61 +659,144 @@ const uint32_t kShaK[64] = {
     0x90befffa, 0xa4506ceb, 0xbef9a3f7, 0xc67178f2};
 const uint32_t kShaIV[8] = {0x6a09e667, 0xbb67ae85, 0x3c6ef372, 0xa54ff53a, 0x510e527f, 0x9b05688c, 0x1f83d9ab, 0x5be0cd19};
 
-// wires: 0 = one, 1..256 = public outputs (digest bits, MSB-first), 257..512 = private message bits, then gates
-void build_sha256_chain(ShaBuilder& sb, uint32_t blocks, const uint8_t msg[32]) {
+// One compression: out = st + rounds(st, W16).
+void sha_compress(ShaBuilder& sb, const ShaBuilder::Word st[8], const ShaBuilder::Word W16[16], ShaBuilder::Word out[8],
+                  uint32_t out_base) {   // out_base != 0: the result bits are the 256 wires from out_base on
+  using Word = ShaBuilder::Word;
+  Word W[64];
+  for (int j = 0; j < 16; j++) W[j] = W16[j];
+  for (int t = 16; t < 64; t++) {
+    const Word s0 = sb.xor3w(ShaBuilder::rotr(W[t - 15], 7), ShaBuilder::rotr(W[t - 15], 18), ShaBuilder::shr(W[t - 15], 3));
+    const Word s1 = sb.xor3w(ShaBuilder::rotr(W[t - 2], 17), ShaBuilder::rotr(W[t - 2], 19), ShaBuilder::shr(W[t - 2], 10));
+    W[t] = sb.add_mod32({W[t - 16], s0, W[t - 7], s1});
+  }
+  Word a = st[0], b = st[1], c = st[2], d = st[3], e = st[4], f = st[5], g = st[6], h = st[7];
+  for (int t = 0; t < 64; t++) {
+    const Word S1 = sb.xor3w(ShaBuilder::rotr(e, 6), ShaBuilder::rotr(e, 11), ShaBuilder::rotr(e, 25));
+    Word chw, mjw;
+    for (int i = 0; i < 32; i++) chw[i] = bit_is_const(e[i]) ? (e[i].b ? f[i] : g[i]) : sb.ch(e[i], f[i], g[i]);
+    const Word S0 = sb.xor3w(ShaBuilder::rotr(a, 2), ShaBuilder::rotr(a, 13), ShaBuilder::rotr(a, 22));
+    for (int i = 0; i < 32; i++) {
+      if (bit_is_const(a[i]) && bit_is_const(b[i]) && bit_is_const(c[i]))
+        mjw[i] = bit_const((a[i].b & b[i].b) | (a[i].b & c[i].b) | (b[i].b & c[i].b));
+      else
+        mjw[i] = sb.maj(a[i], b[i], c[i]);
+    }
+    const Word kw = ShaBuilder::word_const(kShaK[t]);
+    const Word ne = sb.add_mod32({d, h, S1, chw, kw, W[t]});
+    const Word na = sb.add_mod32({h, S1, chw, kw, W[t], S0, mjw});
+    h = g; g = f; f = e; e = ne; d = c; c = b; b = a; a = na;
+  }
+  const Word fin[8] = {a, b, c, d, e, f, g, h};
+  for (int j = 0; j < 8; j++) {
+    if (out_base) {
+      uint32_t outw[32];   // result bit i (weight 2^i) of word j is output bit 32 j + (31 - i)
+      for (int i = 0; i < 32; i++) outw[i] = out_base + 32 * j + (31 - i);
+      out[j] = sb.add_mod32({st[j], fin[j]}, outw);
+    } else {
+      out[j] = sb.add_mod32({st[j], fin[j]});
+    }
+  }
+}
+
+// plain SHA-256 (FIPS 180-4 padding, multi-block) of a message given as bits (MSB-first per byte; wires or
+// constants); the digest bits land on the 256 wires from out_base on
+void sha256_bits(ShaBuilder& sb, const std::vector<Bit>& mbits, uint32_t out_base) {
+  using Word = ShaBuilder::Word;
+  const uint64_t bitlen = mbits.size();
+  const uint32_t nb = (uint32_t)((bitlen / 8 + 9 + 63) / 64);
+  auto padded_bit = [&](uint64_t k) -> Bit {   // bit k (MSB-first) of the padded message
+    if (k < bitlen) return mbits[k];
+    if (k == bitlen) return bit_const(1);
+    const uint64_t total = (uint64_t)nb * 512;
+    if (k >= total - 64) return bit_const((int)((bitlen >> (total - 1 - k)) & 1));
+    return bit_const(0);
+  };
+  Word st[8];
+  for (int j = 0; j < 8; j++) st[j] = ShaBuilder::word_const(kShaIV[j]);
+  for (uint32_t blk = 0; blk < nb; blk++) {
+    Word W16[16], out[8];
+    for (int j = 0; j < 16; j++)
+      for (int k = 0; k < 32; k++) W16[j][31 - k] = padded_bit((uint64_t)blk * 512 + 32 * j + k);
+    sha_compress(sb, st, W16, out, blk + 1 == nb ? out_base : 0u);
+    for (int j = 0; j < 8; j++) st[j] = out[j];
+  }
+}
+
+// wires: 0 = one, 1..256 = public outputs (digest bits, MSB-first), then the private message bits (MSB-first,
+// boolean-constrained), then gates.  chain = true: digest_{i+1} = SHA-256(digest_i), `blocks` times, 32-byte
+// message.  chain = false: plain SHA-256 of the `len`-byte message (padding per FIPS 180-4, len is a
+// compile-time constant of the circuit, like the fixed-length Sha256 gadgets of circomlib).
+void build_sha256(ShaBuilder& sb, bool chain, uint32_t blocks, const uint8_t* msg, uint32_t len) {
   using Word = ShaBuilder::Word;
   for (int i = 0; i < 256; i++) sb.new_wire(0);   // outputs, values filled by the last addition
-  Word m[8];
-  for (int j = 0; j < 8; j++)
-    for (int k = 0; k < 32; k++) {   // message bit 32 j + k (MSB-first) = bit 31 - k of big-endian word j
-      const int v = (msg[4 * j + k / 8] >> (7 - (k & 7))) & 1;
-      const uint32_t wire = sb.new_wire(v);
-      sb.boolean(wire);
-      m[j][31 - k] = bit_wire(wire);
+  std::vector<Bit> mbits((size_t)len * 8);
+  for (uint32_t k = 0; k < len * 8; k++) {
+    const uint32_t wire = sb.new_wire((msg[k / 8] >> (7 - (k & 7))) & 1);
+    sb.boolean(wire);
+    mbits[k] = bit_wire(wire);
+  }
+  Word iv[8];
+  for (int j = 0; j < 8; j++) iv[j] = ShaBuilder::word_const(kShaIV[j]);
+  if (chain) {
+    Word m[8];
+    for (int j = 0; j < 8; j++)
+      for (int k = 0; k < 32; k++) m[j][31 - k] = mbits[32 * j + k];
+    for (uint32_t blk = 0; blk < blocks; blk++) {
+      Word W16[16], out[8];
+      for (int j = 0; j < 8; j++) W16[j] = m[j];
+      W16[8] = ShaBuilder::word_const(0x80000000u);
+      for (int j = 9; j < 15; j++) W16[j] = ShaBuilder::word_const(0);
+      W16[15] = ShaBuilder::word_const(256);
+      sha_compress(sb, iv, W16, out, blk + 1 == blocks ? 1u : 0u);
+      for (int j = 0; j < 8; j++) m[j] = out[j];
     }
-  for (uint32_t blk = 0; blk < blocks; blk++) {
-    Word W[64];
-    for (int j = 0; j < 8; j++) W[j] = m[j];
-    W[8] = ShaBuilder::word_const(0x80000000u);
-    for (int j = 9; j < 15; j++) W[j] = ShaBuilder::word_const(0);
-    W[15] = ShaBuilder::word_const(256);
-    for (int t = 16; t < 64; t++) {
-      const Word s0 = sb.xor3w(ShaBuilder::rotr(W[t - 15], 7), ShaBuilder::rotr(W[t - 15], 18), ShaBuilder::shr(W[t - 15], 3));
-      const Word s1 = sb.xor3w(ShaBuilder::rotr(W[t - 2], 17), ShaBuilder::rotr(W[t - 2], 19), ShaBuilder::shr(W[t - 2], 10));
-      W[t] = sb.add_mod32({W[t - 16], s0, W[t - 7], s1});
-    }
-    Word st[8];
-    for (int j = 0; j < 8; j++) st[j] = ShaBuilder::word_const(kShaIV[j]);
-    Word a = st[0], b = st[1], c = st[2], d = st[3], e = st[4], f = st[5], g = st[6], h = st[7];
-    for (int t = 0; t < 64; t++) {
-      const Word S1 = sb.xor3w(ShaBuilder::rotr(e, 6), ShaBuilder::rotr(e, 11), ShaBuilder::rotr(e, 25));
-      Word chw, mjw;
-      for (int i = 0; i < 32; i++) chw[i] = bit_is_const(e[i]) ? (e[i].b ? f[i] : g[i]) : sb.ch(e[i], f[i], g[i]);
-      const Word S0 = sb.xor3w(ShaBuilder::rotr(a, 2), ShaBuilder::rotr(a, 13), ShaBuilder::rotr(a, 22));
-      for (int i = 0; i < 32; i++) {
-        if (bit_is_const(a[i]) && bit_is_const(b[i]) && bit_is_const(c[i]))
-          mjw[i] = bit_const((a[i].b & b[i].b) | (a[i].b & c[i].b) | (b[i].b & c[i].b));
-        else
-          mjw[i] = sb.maj(a[i], b[i], c[i]);
-      }
-      const Word kw = ShaBuilder::word_const(kShaK[t]);
-      const Word ne = sb.add_mod32({d, h, S1, chw, kw, W[t]});
-      const Word na = sb.add_mod32({h, S1, chw, kw, W[t], S0, mjw});
-      h = g; g = f; f = e; e = ne; d = c; c = b; b = a; a = na;
-    }
-    const Word fin[8] = {a, b, c, d, e, f, g, h};
-    for (int j = 0; j < 8; j++) {
-      if (blk + 1 == blocks) {
-        uint32_t outw[32];   // result bit i (weight 2^i) of word j is output bit 32 j + (31 - i)
-        for (int i = 0; i < 32; i++) outw[i] = 1 + 32 * j + (31 - i);
-        m[j] = sb.add_mod32({st[j], fin[j]}, outw);
-      } else {
-        m[j] = sb.add_mod32({st[j], fin[j]});
-      }
-    }
+  } else {
+    sha256_bits(sb, mbits, 1);
   }
   sb.c.n = (uint32_t)sb.w.size();
   sb.c.p = 256;
+  sb.c.m = (uint32_t)sb.c.rowA.size() - 1;
+}
+
+// The NZCP circuit's PUBLIC INTERFACE on a fixed pass layout (/root/reference/circuits/nzcptpl.circom:447-602,
+// /root/reference/test/nzcp.js:41-47): public signals [0..255] = SHA-256("given,family,dob") bits,
+// [256..511] = SHA-256(ToBeSigned) bits, [512] = exp.  The reference finds the three strings and `exp` by CBOR
+// parsing inside the circuit (cbortpl.circom, not restated here); this circuit takes their byte offsets as
+// circuit constants instead -- sound for passes of that layout: the credential string is wired to the SAME
+// ToBeSigned bit wires at seg_off[k] (no copies), commas are constants, and exp is one linear row over the
+// 32 ToBeSigned bits at exp_off.
+void build_nzcp_fixed_layout(ShaBuilder& sb, const uint8_t* tbs, uint32_t len, const uint32_t seg_off[3],
+                             const uint32_t seg_len[3], uint32_t exp_off) {
+  for (int i = 0; i < 512; i++) sb.new_wire(0);   // the two digests
+  const uint32_t exp_wire = sb.new_wire(0);
+  std::vector<Bit> mbits((size_t)len * 8);
+  for (uint32_t k = 0; k < len * 8; k++) {
+    const uint32_t wire = sb.new_wire((tbs[k / 8] >> (7 - (k & 7))) & 1);
+    sb.boolean(wire);
+    mbits[k] = bit_wire(wire);
+  }
+  std::vector<Bit> subj;
+  for (int sgi = 0; sgi < 3; sgi++) {
+    if (sgi)
+      for (int k = 0; k < 8; k++) subj.push_back(bit_const((',' >> (7 - k)) & 1));
+    for (uint32_t k = 0; k < seg_len[sgi] * 8; k++) subj.push_back(mbits[(size_t)seg_off[sgi] * 8 + k]);
+  }
+  sha256_bits(sb, subj, 1);
+  sha256_bits(sb, mbits, 257);
+  uint64_t exp = 0;
+  Lin a, b, z;
+  for (int k = 0; k < 32; k++) {
+    const Bit& bt = mbits[(size_t)exp_off * 8 + k];
+    exp |= (uint64_t)sb.val(bt) << (31 - k);
+    ShaBuilder::add(a, bt, (int64_t)1 << (31 - k));
+  }
+  sb.w[exp_wire] = exp;
+  a.t.push_back({exp_wire, -1});
+  b.t.push_back({0u, 1});
+  sb.constrain(a, b, z);
+  sb.c.n = (uint32_t)sb.w.size();
+  sb.c.p = 513;
   sb.c.m = (uint32_t)sb.c.rowA.size() - 1;
 }
 
@@ -746,19 +829,13 @@ void write_r1cs(const Circuit& c, uint32_t n_pub_out, uint32_t n_pub_in, Buf& b)
 }  // namespace
 }  // namespace g16
 
-// Test-only: the SHA-256 chain circuit above, keyed with a known trapdoor.  Any output pointer may be
-// NULL.  r1cs: iden3 .r1cs v1 image of the same constraint system (for snarkjs / tools/r1cs_setup.py).
-extern "C" int g16_sha256_chain_setup(uint32_t blocks, const uint8_t msg[32], uint64_t seed, int threads,
-                                      uint8_t** zkey, size_t* zkey_len, uint8_t** wtns, size_t* wtns_len,
-                                      uint8_t** vkey, size_t* vkey_len, uint8_t** r1cs, size_t* r1cs_len) {
-  if (!msg || blocks == 0 || blocks > 4096) { set_error("sha256 chain: bad arguments"); return G16_E_ARG; }
-  ShaBuilder sb;
-  build_sha256_chain(sb, blocks, msg);
-  if ((uint64_t)sb.c.m + sb.c.p + 1 > ((uint64_t)1 << 27)) { set_error("sha256 chain: circuit too large"); return G16_E_ARG; }
+static int sha_emit(ShaBuilder& sb, uint64_t seed, int threads, uint8_t** zkey, size_t* zkey_len, uint8_t** wtns,
+                    size_t* wtns_len, uint8_t** vkey, size_t* vkey_len, uint8_t** r1cs, size_t* r1cs_len) {
+  if ((uint64_t)sb.c.m + sb.c.p + 1 > ((uint64_t)1 << 27)) { set_error("sha256 circuit too large"); return G16_E_ARG; }
   if (wtns && wtns_len) {
     std::vector<FrM> w(sb.w.size());
     const FrM one = fr_one(), zero = fp_zero<FrParams>();
-    for (size_t i = 0; i < w.size(); i++) w[i] = sb.w[i] ? one : zero;
+    for (size_t i = 0; i < w.size(); i++) w[i] = sb.w[i] == 0 ? zero : (sb.w[i] == 1 ? one : fr_u64(sb.w[i]));
     Buf b;
     write_wtns(w, b);
     *wtns = b.p;
@@ -766,12 +843,48 @@ extern "C" int g16_sha256_chain_setup(uint32_t blocks, const uint8_t msg[32], ui
   }
   if (r1cs && r1cs_len) {
     Buf b;
-    write_r1cs(sb.c, 256, 0, b);
+    write_r1cs(sb.c, sb.c.p, 0, b);
     *r1cs = b.p;
     *r1cs_len = b.len;
   }
   if (zkey && zkey_len) return setup_core(sb.c, seed, threads, zkey, zkey_len, vkey, vkey_len);
   return G16_OK;
+}
+
+// Test-only: the SHA-256 circuits above, keyed with a known trapdoor.  Any output pointer may be NULL.
+// r1cs: iden3 .r1cs v1 image of the same constraint system (for snarkjs / tools/r1cs_setup.py).
+extern "C" int g16_sha256_chain_setup(uint32_t blocks, const uint8_t msg[32], uint64_t seed, int threads,
+                                      uint8_t** zkey, size_t* zkey_len, uint8_t** wtns, size_t* wtns_len,
+                                      uint8_t** vkey, size_t* vkey_len, uint8_t** r1cs, size_t* r1cs_len) {
+  if (!msg || blocks == 0 || blocks > 4096) { set_error("sha256 chain: bad arguments"); return G16_E_ARG; }
+  ShaBuilder sb;
+  build_sha256(sb, true, blocks, msg, 32);
+  return sha_emit(sb, seed, threads, zkey, zkey_len, wtns, wtns_len, vkey, vkey_len, r1cs, r1cs_len);
+}
+
+extern "C" int g16_sha256_message_setup(const uint8_t* msg, uint32_t len, uint64_t seed, int threads,
+                                        uint8_t** zkey, size_t* zkey_len, uint8_t** wtns, size_t* wtns_len,
+                                        uint8_t** vkey, size_t* vkey_len, uint8_t** r1cs, size_t* r1cs_len) {
+  if ((!msg && len) || len > (1u << 20)) { set_error("sha256 message: bad arguments"); return G16_E_ARG; }
+  ShaBuilder sb;
+  const uint8_t none = 0;
+  build_sha256(sb, false, 0, msg ? msg : &none, len);
+  return sha_emit(sb, seed, threads, zkey, zkey_len, wtns, wtns_len, vkey, vkey_len, r1cs, r1cs_len);
+}
+
+extern "C" int g16_nzcp_fixed_layout_setup(const uint8_t* tbs, uint32_t len, const uint32_t seg_off[3],
+                                          const uint32_t seg_len[3], uint32_t exp_off, uint64_t seed, int threads,
+                                          uint8_t** zkey, size_t* zkey_len, uint8_t** wtns, size_t* wtns_len,
+                                          uint8_t** vkey, size_t* vkey_len, uint8_t** r1cs, size_t* r1cs_len) {
+  if (!tbs || !seg_off || !seg_len || len == 0 || len > 4096 || (uint64_t)exp_off + 4 > len) {
+    set_error("nzcp fixed layout: bad arguments");
+    return G16_E_ARG;
+  }
+  for (int k = 0; k < 3; k++)
+    if ((uint64_t)seg_off[k] + seg_len[k] > len) { set_error("nzcp fixed layout: segment out of range"); return G16_E_ARG; }
+  ShaBuilder sb;
+  build_nzcp_fixed_layout(sb, tbs, len, seg_off, seg_len, exp_off);
+  return sha_emit(sb, seed, threads, zkey, zkey_len, wtns, wtns_len, vkey, vkey_len, r1cs, r1cs_len);
 }
 
 // ------------------------------------------------------------------ .r1cs reader

@@ -172,3 +172,68 @@ def test_trapdoor_kat_medium(amd):
     assert proof == f.proof_obj(*exp)
     assert pub == [str(x) for x in w[1:p + 1]]
     prover.close()
+
+
+def test_public_json_matches_reference_golden_tobesigned_hash(amd):
+    """A REAL circuit proved on the GPU, pinned by the reference's own golden data: SHA-256 over the MoH example
+    pass's ToBeSigned (314 bytes, 6 compressions, ~155 k constraints).  public.json must be the bits of
+    271ce33d...f3ee -- the `toBeSignedSha256` slice of the NZCP circuit's public signals
+    (/root/reference/test/nzcp.js:41-47, value from SURVEY App. D.2) -- and the proof must verify and equal
+    the C oracle's bytes."""
+    import ctypes
+    import os
+    from test_cpu_sha256_circuit import EXAMPLE_TBS_SHA256, example_to_be_signed
+    tbs = example_to_be_signed()
+    out = amd.sha256_message_setup(tbs, 4242)
+    zkey, wtns = out["zkey"], out["wtns"]
+    vkey = out["vkey"]
+    vk = {"alpha1": f.g1_from_lem(vkey[0:64]), "beta2": f.g2_from_lem(vkey[64:192]),
+          "gamma2": f.g2_from_lem(vkey[192:320]), "delta2": f.g2_from_lem(vkey[320:448]),
+          "IC": [f.g1_from_lem(vkey[448 + 64 * i:512 + 64 * i]) for i in range(257)]}
+    rng = synth.Xoshiro(4244)
+    r, s = rng.rand_fr(), rng.rand_fr()
+    prover = amd.Prover(zkey)
+    assert prover.info.n_public == 256 and prover.info.domain_size == 1 << 18
+    proof, pub = prover.prove(wtns, f.le(r), f.le(s))
+    want = [str((byte >> (7 - k)) & 1) for byte in bytes.fromhex(EXAMPLE_TBS_SHA256) for k in range(8)]
+    assert pub == want
+    pts = (f.g1_from_obj(proof["pi_a"]), f.g2_from_obj(proof["pi_b"]), f.g1_from_obj(proof["pi_c"]))
+    assert g.verify(vk, [int(x) for x in pub], pts)
+    # a proof for a different message must not verify against these public signals
+    bad = amd.sha256_message_setup(tbs[:-1] + bytes([tbs[-1] ^ 1]), 4242, want_zkey=False)["wtns"]
+    proof2, pub2 = prover.prove(bad, f.le(r), f.le(s))
+    assert pub2 != want
+    pts2 = (f.g1_from_obj(proof2["pi_a"]), f.g2_from_obj(proof2["pi_b"]), f.g1_from_obj(proof2["pi_c"]))
+    assert not g.verify(vk, [int(x) for x in want], pts2)
+    assert g.verify(vk, [int(x) for x in pub2], pts2)
+    lib_path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "_build", "libg16oracle.so")
+    if os.path.exists(lib_path):
+        olib = ctypes.CDLL(lib_path)
+        olib.g16o_prove.argtypes = [ctypes.c_char_p, ctypes.c_size_t, ctypes.c_char_p, ctypes.c_size_t,
+                                    ctypes.c_char_p, ctypes.c_char_p, ctypes.c_char_p, ctypes.c_char_p, ctypes.c_int]
+        obuf, opub = ctypes.create_string_buffer(256), ctypes.create_string_buffer(256 * 32)
+        assert olib.g16o_prove(zkey, len(zkey), wtns, len(wtns), f.le(r), f.le(s), obuf, opub, os.cpu_count() or 1) == 0
+        assert f.proof_obj(f.g1_from_obj(proof["pi_a"]), f.g2_from_obj(proof["pi_b"]), f.g1_from_obj(proof["pi_c"])) == proof
+        A = (f.from_le(obuf.raw[0:32]), f.from_le(obuf.raw[32:64]))
+        assert proof["pi_a"][:2] == [str(A[0]), str(A[1])]
+    prover.close()
+
+
+def test_public_json_equals_reference_example_pass(amd):
+    """public.json of a GPU proof == the 513 values the reference's test expects for the MoH example pass
+    (/root/reference/test/nzcp.js:41-49; values SURVEY App. D.2), from the fixed-layout NZCP interface circuit
+    over the pass's ToBeSigned; proof pairing-verified against the setup's verification key."""
+    from test_cpu_sha256_circuit import (EXAMPLE_EXP_OFF, EXAMPLE_SEGS, example_public_signals, example_to_be_signed)
+    out = amd.nzcp_fixed_layout_setup(example_to_be_signed(), EXAMPLE_SEGS, EXAMPLE_EXP_OFF, 777)
+    vkey = out["vkey"]
+    vk = {"alpha1": f.g1_from_lem(vkey[0:64]), "beta2": f.g2_from_lem(vkey[64:192]),
+          "gamma2": f.g2_from_lem(vkey[192:320]), "delta2": f.g2_from_lem(vkey[320:448]),
+          "IC": [f.g1_from_lem(vkey[448 + 64 * i:512 + 64 * i]) for i in range(514)]}
+    prover = amd.Prover(out["zkey"])
+    assert prover.info.n_public == 513
+    proof, pub = prover.prove(out["wtns"])
+    assert pub == [str(x) for x in example_public_signals()]
+    assert amd.stringify(pub).startswith('[\n "0",\n "1",')     # 5f = 0101 1111, JSON.stringify(x, null, 1) layout
+    pts = (f.g1_from_obj(proof["pi_a"]), f.g2_from_obj(proof["pi_b"]), f.g1_from_obj(proof["pi_c"]))
+    assert g.verify(vk, [int(x) for x in pub], pts)
+    prover.close()
