@@ -97,6 +97,7 @@ struct MsmInstance {
   uint32_t n_ext = 0;          // pf * n = entries per row = points in d_bases
   uint32_t nbuckets = 0;       // per window = 2^(c-1)
   uint32_t task_len = 0;
+  bool dense = true;           // MsmConfig::dense (the H-MSM)
 };
 size_t msm_point_bytes(int curve);   // XYZZ bytes: 128 (G1) / 256 (G2)
 // bases_host: n_total affine points in file layout; keeps only non-infinity ones.

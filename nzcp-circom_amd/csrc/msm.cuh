@@ -70,10 +70,21 @@ struct MsmWorkspace {
 struct U256 { uint32_t v[8]; };
 
 static constexpr uint32_t kSegLenDefault = 16;   // buckets per reduce segment (G16_SEG_LEN overrides, sweeps)
-inline uint32_t msm_seg_len() {
-  static uint32_t v = 0;
-  if (!v) { const char* e = getenv("G16_SEG_LEN"); v = e ? (uint32_t)atoi(e) : kSegLenDefault; if (v < 1) v = 1; if (v > 64) v = 64; }
-  return v;
+// `dense` (the H-MSM): its reduce is the exposed tail of the proof, so shorter segments (more lanes, shorter
+// chains) pay; the witness MSMs reduce while the H-MSM accumulates, where extra VALU work only competes.
+inline uint32_t msm_seg_len(bool dense = false) {
+  static uint32_t v = 0, vd = 0;
+  if (!v) {
+    const char* e = getenv("G16_SEG_LEN");
+    v = e ? (uint32_t)atoi(e) : kSegLenDefault;
+    if (v < 1) v = 1;
+    if (v > 64) v = 64;
+    const char* ed = getenv("G16_SEG_LEN_DENSE");
+    vd = ed ? (uint32_t)atoi(ed) : v;
+    if (vd < 1) vd = 1;
+    if (vd > 64) vd = 64;
+  }
+  return dense ? vd : v;
 }
 
 __device__ __forceinline__ uint32_t msm_extract(const uint32_t s[8], int pos, int c) {
@@ -629,7 +640,7 @@ int msm_launch_t(const MsmInstance& m, MsmWorkspace* ws, const Fr* d_scalars, hi
   using CPT = XYZZ<typename F::CanonOps>;
   ws->out_bytes = (size_t)WT * sizeof(CPT);
   if (m.n == 0) return G16_OK;
-  const uint32_t seg_len = msm_seg_len();
+  const uint32_t seg_len = msm_seg_len(m.dense);
   const uint32_t nseg = (B + seg_len - 1) / seg_len;
   U256 K;
   msm_make_K(m.c, m.Ws, K);

@@ -56,6 +56,7 @@ int msm_instance_create(MsmInstance& m, int curve, const uint8_t* bases_host, ui
                         uint32_t scalar_offset, const MsmConfig& cfg) {
   const size_t psz = curve == 2 ? sizeof(G2Affine) : sizeof(G1Affine);
   m.curve = curve;
+  m.dense = cfg.dense;
   std::vector<uint32_t> src;
   std::vector<uint8_t> packed;
   src.reserve(n_total);
@@ -137,7 +138,8 @@ int msm_workspace_create(MsmWorkspace** out, const MsmInstance* insts, int ninst
     const uint64_t nb = (uint64_t)(m.W + 1) * m.nbuckets;   // + the ones window
     const uint64_t entries = (uint64_t)m.n * m.Ws;
     const uint64_t tasks = nb + entries / (m.task_len >= 16 ? m.task_len / 4 : 4) + 64;   // worst case of the graded lengths
-    const uint64_t nseg = (m.nbuckets + msm_seg_len() - 1) / msm_seg_len();
+    const uint32_t sl = msm_seg_len(true) < msm_seg_len(false) ? msm_seg_len(true) : msm_seg_len(false);   // the shorter: more segments
+    const uint64_t nseg = (m.nbuckets + sl - 1) / sl;
     const size_t pb = m.curve == 2 ? sizeof(G2XYZZ29) : sizeof(G1XYZZ29);   // device-side (lazy) points
     const size_t cpb = msm_point_bytes(m.curve);                             // canonical, host-visible
     if (entries > ws->max_entries) ws->max_entries = (uint32_t)entries;
