@@ -351,7 +351,7 @@ static __global__ __launch_bounds__(256) void msm_task_fill_kernel(const uint32_
 static constexpr uint32_t kTaskChunk = 64;
 
 template <class F>
-__global__ __launch_bounds__(64, F::kAccumWavesPerSimd) void msm_accumulate_kernel(const Affine<F>* __restrict__ bases,
+__global__ __launch_bounds__(64, F::kAccumWavesPerSimd) void msm_accumulate_kernel(const PackedAffine<F>* __restrict__ bases,
                                                             const uint32_t* __restrict__ sorted,
                                                             const uint32_t* __restrict__ toff, uint32_t nb,
                                                             const uint2* __restrict__ task_desc,
@@ -385,7 +385,8 @@ __global__ __launch_bounds__(64, F::kAccumWavesPerSimd) void msm_accumulate_kern
       cur = desc.x;
       end = desc.x + desc.y;
       const uint32_t idx = sorted[cur++];
-      Affine<F> p = bases[idx & 0x7fffffffu];
+      Affine<F> p;
+      a29_unpack(p, bases[idx & 0x7fffffffu]);
       if (idx >> 31) a29_neg(p);
       acc.x = p.x; acc.y = p.y; acc.zz = F::one(); acc.zzz = F::one();
       bad = false;
@@ -424,7 +425,8 @@ __global__ __launch_bounds__(64, F::kAccumWavesPerSimd) void msm_accumulate_kern
     //    hide the two dependent loads.)
     if (my_task != kNone && cur != end) {
       const uint32_t idx = sorted[cur++];
-      Affine<F> p = bases[idx & 0x7fffffffu];
+      Affine<F> p;
+      a29_unpack(p, bases[idx & 0x7fffffffu]);
       if (idx >> 31) a29_neg(p);
       bad |= x29_madd_fast(acc, p);
     }
@@ -434,7 +436,7 @@ __global__ __launch_bounds__(64, F::kAccumWavesPerSimd) void msm_accumulate_kern
 // The flagged tasks again, with the complete addition (doubling, cancellation, infinity): a handful per
 // proof at most, one lane each.
 template <class F>
-__global__ __launch_bounds__(64) void msm_redo_kernel(const Affine<F>* __restrict__ bases,
+__global__ __launch_bounds__(64) void msm_redo_kernel(const PackedAffine<F>* __restrict__ bases,
                                                       const uint32_t* __restrict__ sorted,
                                                       const uint2* __restrict__ task_desc,
                                                       const uint32_t* __restrict__ queue,
@@ -448,7 +450,8 @@ __global__ __launch_bounds__(64) void msm_redo_kernel(const Affine<F>* __restric
     x29_set_inf(acc);
     for (uint32_t e = d.x; e < d.x + d.y; e++) {
       const uint32_t idx = sorted[e];
-      Affine<F> p = bases[idx & 0x7fffffffu];
+      Affine<F> p;
+      a29_unpack(p, bases[idx & 0x7fffffffu]);
       if (idx >> 31) a29_neg(p);
       x29_madd(acc, p);
     }
@@ -588,12 +591,14 @@ __global__ __launch_bounds__(64) void msm_wave_reduce_kernel(const XYZZ<F>* __re
 // bases: canonical affine image (zkey bytes) -> lazy 9x29 representation, once at create
 template <class F>
 __global__ __launch_bounds__(256) void msm_convert_bases_kernel(const Affine<typename F::CanonOps>* __restrict__ in,
-                                                                Affine<F>* __restrict__ out, uint32_t n) {
+                                                                PackedAffine<F>* __restrict__ out, uint32_t n) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   Affine<F> r;
   a29_from_canon<F, typename F::CanonOps>(r, in[i]);
-  out[i] = r;
+  PackedAffine<F> pk;
+  a29_pack(pk, r);
+  out[i] = pk;
 }
 // Window precomputation (once at create): out[i] = 2^ndbl * in[i], affine, on the canonical field (exact
 // arithmetic, fp.cuh / ec.cuh; one Fermat inversion per point -- create-time only).
@@ -691,10 +696,10 @@ int msm_launch_t(const MsmInstance& m, MsmWorkspace* ws, const Fr* d_scalars, hi
   G16_HIP(hipEventRecord(ws->ev_sorted, st));
   if (ws->accum_gate) G16_HIP(hipStreamWaitEvent(st, ws->accum_gate, 0));
   G16_HIP(hipEventRecord(ws->ev0, st));
-  msm_accumulate_kernel<F><<<(unsigned)waves, 64, 0, st>>>((const Affine<F>*)m.d_bases, ws->d_sorted, ws->d_toff, nb,
+  msm_accumulate_kernel<F><<<(unsigned)waves, 64, 0, st>>>((const PackedAffine<F>*)m.d_bases, ws->d_sorted, ws->d_toff, nb,
                                                             ws->d_task_desc, ws->d_queue, ws->d_redo, (PT*)ws->d_partial);
   G16_HIP(hipEventRecord(ws->ev1, st));
-  msm_redo_kernel<F><<<64, 64, 0, st>>>((const Affine<F>*)m.d_bases, ws->d_sorted, ws->d_task_desc, ws->d_queue,
+  msm_redo_kernel<F><<<64, 64, 0, st>>>((const PackedAffine<F>*)m.d_bases, ws->d_sorted, ws->d_task_desc, ws->d_queue,
                                         ws->d_redo, (PT*)ws->d_partial);
   G16_HIP(hipMemsetAsync(ws->d_heavy, 0, 4, st));
   mark(4);

@@ -9,7 +9,7 @@ size_t msm_point_bytes(int curve) { return curve == 2 ? sizeof(G2XYZZ) : sizeof(
 
 int msm_convert_bases_g2(const void* in, void* out, uint32_t n);
 static int msm_convert_bases_g1(const void* in, void* out, uint32_t n) {
-  msm_convert_bases_kernel<Fq29Ops><<<(n + 255) / 256, 256>>>((const G1Affine*)in, (G1Affine29*)out, n);
+  msm_convert_bases_kernel<Fq29Ops><<<(n + 255) / 256, 256>>>((const G1Affine*)in, (PackedAffine<Fq29Ops>*)out, n);
   G16_HIP(hipGetLastError());
   G16_HIP(hipDeviceSynchronize());
   return G16_OK;
@@ -98,7 +98,7 @@ int msm_instance_create(MsmInstance& m, int curve, const uint8_t* bases_host, ui
     // upload the canonical image, convert once on the device to the kernels' 9x29 representation
     void* tmp = nullptr;
     void* tmp2 = nullptr;
-    const size_t lazy_pt = curve == 2 ? sizeof(G2Affine29) : sizeof(G1Affine29);
+    const size_t lazy_pt = curve == 2 ? sizeof(PackedAffine<Fq2x29Ops>) : sizeof(PackedAffine<Fq29Ops>);
     G16_HIP(hipMalloc(&tmp, packed.size()));
     if (m.pf > 1) G16_HIP(hipMalloc(&tmp2, packed.size()));
     G16_HIP(hipMalloc(&m.d_bases, (size_t)m.n_ext * lazy_pt));

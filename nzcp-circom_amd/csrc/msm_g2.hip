@@ -8,7 +8,7 @@ int msm_launch_g2(const MsmInstance& m, MsmWorkspace* ws, const Fr* d_scalars, h
   return msm_launch_t<Fq2x29Ops>(m, ws, d_scalars, st);
 }
 int msm_convert_bases_g2(const void* in, void* out, uint32_t n) {
-  msm_convert_bases_kernel<Fq2x29Ops><<<(n + 255) / 256, 256>>>((const G2Affine*)in, (G2Affine29*)out, n);
+  msm_convert_bases_kernel<Fq2x29Ops><<<(n + 255) / 256, 256>>>((const G2Affine*)in, (PackedAffine<Fq2x29Ops>*)out, n);
   G16_HIP(hipGetLastError());
   G16_HIP(hipDeviceSynchronize());
   return G16_OK;

@@ -43,6 +43,33 @@ template <class F29ops, class FC> static void curve_test(const Affine<FC>& gen, 
     xyzz_mul_scalar(t, gen, k);
     xyzz_to_affine(pool[i], t);
     a29_from_canon<F29ops, FC>(pool29[i], pool[i]);
+    PackedAffine<F29ops> pk;           // the accumulate kernel adds the fast formula on unpacked points
+    a29_pack(pk, pool29[i]);
+    Affine<F29ops> back;
+    a29_unpack(back, pk);
+    CHECK(memcmp(&back, &pool29[i], sizeof(back)) == 0);
+  }
+  {  // x29_madd_fast == x29_madd away from the exceptional cases; flags a doubling and a cancellation
+    XYZZ<F29ops> a1, a2;
+    x29_set_inf(a1);
+    x29_madd(a1, pool29[0]);
+    a2 = a1;
+    for (int i = 1; i < NP; i++) {
+      x29_madd(a1, pool29[i]);
+      CHECK(!x29_madd_fast(a2, pool29[i]));
+      XYZZ<FC> c1;
+      x29_to_canon<F29ops, FC>(c1, a1);
+      CHECK((same_point<F29ops, FC>(a2, c1)));
+    }
+    XYZZ<F29ops> d;
+    x29_set_inf(d);
+    x29_madd(d, pool29[3]);
+    XYZZ<F29ops> d2 = d;
+    CHECK(x29_madd_fast(d2, pool29[3]));            // P + P
+    Affine<F29ops> neg = pool29[3];
+    a29_neg(neg);
+    d2 = d;
+    CHECK(x29_madd_fast(d2, neg));                   // P + (-P)
   }
   XYZZ<FC> acc, other;
   XYZZ<F29ops> acc29, other29;
@@ -87,6 +114,10 @@ int main() {
     const Fq a = rand_fq(), b = rand_fq();
     const F29 A = f29_from_fq(a), B = f29_from_fq(b);
     CHECK(fp_eq(f29_to_fq(A), a));
+    {  // resident storage: nine 29-bit limbs <-> eight 32-bit words, lossless below 2^256
+      const F29 U = f29_unpack(f29_pack(A));
+      for (int i = 0; i < 9; i++) CHECK(U.l[i] == A.l[i]);
+    }
     CHECK(fp_eq(f29_to_fq(f29_mul(A, B)), fp_mul(a, b)));
     CHECK(fp_eq(f29_to_fq(f29_sqr(A)), fp_mul(a, a)));
     CHECK(fp_eq(f29_to_fq(f29_sqr_mul(A, B, f29_add(A, B))), fp_add(fp_mul(a, a), fp_mul(b, fp_add(a, b)))));
