@@ -57,9 +57,9 @@ traffic = {
     "avg_traffic_bytes_per_launch": int(sum(f + w for f, w in zip(fetch, write)) / max(1, len(fetch))),
     "method": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum in separate passes with "
               "--kernel-trace (MI355X_MICROARCH.md HBM section); counters are KiB -> x1024. FETCH_SIZE is reported RAW: "
-              "the guide's x2 correction is calibrated for 16 B/lane coalesced streams only; these are 80-byte random "
-              "gathers (5 x dwordx4 per lane), for which TCC_MISS_sum x 64 B gives the same figure within ~5 %, so no "
-              "correction is applied.",
+              "the guide's x2 correction is calibrated for 16 B/lane coalesced streams only; these are 64-byte random "
+              "gathers (4 x dwordx4 per lane, one aligned 64-byte sector per point), for which TCC_MISS_sum x 64 B gives "
+              "the same figure within ~5 %, so no correction is applied.",
     "source": f"profiles/{tag}_pmc_accumulate.txt (tools/profile_round.sh + tools/pmc_summary.py)",
 }
 json.dump(traffic, open(os.path.join(prof, f"{tag}_pmc_traffic.json"), "w"), indent=1)
