@@ -118,3 +118,30 @@ def test_nzcp_input_builder_example_pass():
     assert "%064x" % int(o["h1"], 2) == "5fb355822221720ea4ce6734e5a09e459d452574a19310c0cea7c141f43a3dab"
     assert "%064x" % int(o["h2"], 2) == "271ce33d671a2d3b816d788135f4343e14bc66802f8cd841faac939e8c11f3ee"
     assert "circuit maximum is 300" in o["tooLong"]
+
+
+@needs_node
+@pytest.mark.gpu
+def test_node_prove_of_example_pass_matches_the_pass(addon, amd, tmp_path):
+    """End to end in the reference's host language: `groth16.prove` (N-API -> C ABI -> HIP) on the fixed-layout NZCP
+    interface circuit over the MoH example pass, then nzcpInput.publicSignalsMatchPass(publicSignals, uri) -- the
+    check /root/reference/test/nzcp.js:41-49 makes on the circuit's outputs."""
+    from test_cpu_sha256_circuit import EXAMPLE_EXP_OFF, EXAMPLE_SEGS, example_public_signals, example_to_be_signed
+    out = amd.nzcp_fixed_layout_setup(example_to_be_signed(), EXAMPLE_SEGS, EXAMPLE_EXP_OFF, 31337)
+    zk, wt = tmp_path / "nzcp_fixed.zkey", tmp_path / "nzcp_fixed.wtns"
+    zk.write_bytes(out["zkey"])
+    wt.write_bytes(out["wtns"])
+    uri = open(golden_path("example_pass_uri.txt")).read().strip()
+    script = f"""
+    const {{ groth16 }} = require({json.dumps(JS)});
+    const nz = require({json.dumps(os.path.join(JS, "nzcpInput.js"))});
+    (async () => {{
+      const {{ proof, publicSignals }} = await groth16.prove({json.dumps(str(zk))}, {json.dumps(str(wt))});
+      console.log(JSON.stringify({{ok: nz.publicSignalsMatchPass(publicSignals, {json.dumps(uri)}), n: publicSignals.length,
+                                  last: publicSignals[512], protocol: proof.protocol, curve: proof.curve}}));
+    }})();
+    """
+    r = run_node(script)
+    assert r.returncode == 0, r.stderr
+    o = json.loads(r.stdout)
+    assert o == {"ok": True, "n": 513, "last": str(example_public_signals()[512]), "protocol": "groth16", "curve": "bn128"}
