@@ -81,18 +81,6 @@ template <class C = Fq29C> G16_HD F29 f29_one() {
 
 // full carry ripple: limbs 0..7 below 2^29 afterwards (inputs: any limbs whose running sums fit 32 bits)
 G16_HD void f29_carry(F29& a) {
-#if defined(G16_F29_PAR_CARRY)
-  {  // experiment: one parallel carry step -- limbs end below 2^29 + 2^3 instead of exactly normalised
-    uint32_t c[8];
-#pragma unroll
-    for (int i = 0; i < 8; i++) c[i] = a.l[i] >> 29;
-#pragma unroll
-    for (int i = 0; i < 8; i++) a.l[i] &= kM29;
-#pragma unroll
-    for (int i = 0; i < 8; i++) a.l[i + 1] += c[i];
-    return;
-  }
-#endif
   uint32_t c = 0;
 #pragma unroll
   for (int i = 0; i < 8; i++) {

@@ -477,7 +477,8 @@ inline uint32_t msm_light_max(const MsmInstance& m) {
   const uint64_t tasks = ((uint64_t)m.n * (uint32_t)m.Ws) / m.task_len;
   const uint64_t avg = tasks / ((uint64_t)m.W * m.nbuckets) + 1;
   uint64_t v = 2 * avg + 4;
-  if (getenv("G16_GRADED_TASKS")) v *= 4;   // graded task lengths: up to 4x more partials in the last buckets
+  static const bool graded = getenv("G16_GRADED_TASKS") != nullptr;
+  if (graded) v *= 4;   // graded task lengths: up to 4x more partials in the last buckets
   if (v < kLightTasks) v = kLightTasks;
   if (v > 48) v = 48;
   return (uint32_t)v;

@@ -595,7 +595,8 @@ static int collect_h_msm(g16_prover* P, ProofCtx& c, Partial& out) {
   (void)hipEventElapsedTime(&c.tm.qap_ms, c.ev[2], c.ev[3]);
   (void)hipEventElapsedTime(&c.tm.ntt_ms, c.ev[3], c.ev[4]);
   (void)hipEventElapsedTime(&c.tm.total_ms, c.ev[2], c.ev[5]);
-  if (getenv("G16_TRACE_HOST")) {
+  static const bool trace_dev = getenv("G16_TRACE_HOST") != nullptr;
+  if (trace_dev) {
     static const char* nm[5] = {"A", "B1", "B2", "C", "H"};
     float t_ntt0 = 0, t_ntt1 = 0;
     (void)hipEventElapsedTime(&t_ntt0, c.ev[2], c.ev[3]);
