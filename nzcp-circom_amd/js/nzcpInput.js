@@ -125,4 +125,89 @@ function publicSignalsMatchPass(publicSignals, uri) {
   return publicSignals.length === want.length && publicSignals.every((v, i) => String(v) === want[i]);
 }
 
-module.exports = { base32Decode, parsePassURI, toBeSigned, circuitInput, claims, expectedPublicSignals, publicSignalsMatchPass };
+// ---------------------------------------------------------------- synthetic passes (SURVEY 8f row 1, second half)
+// Real live passes are private (/root/reference/.env.example), so the live FORMAT is generated: same CWT
+// structure as the MoH example pass, with the live issuer "did:web:nzcp.identity.health.nz" (31 chars) and an
+// 8-byte kid -- which is what moves the claims map to offset 30 of ToBeSigned (ClaimsSkip,
+// /root/reference/circuits/nzcptpl.circom:438) and exp / vc / credentialSubject to 72 / 80 / 250
+// (/root/reference/test/nzcp.js:103,158,230).  The signature is random bytes: the circuit never checks it
+// (/root/reference/README.md:19-22).
+function base32Encode(buf) {
+  let out = "", acc = 0, nbits = 0;
+  for (const byte of buf) {
+    acc = (acc << 8) | byte;
+    nbits += 8;
+    while (nbits >= 5) { nbits -= 5; out += B32[(acc >> nbits) & 31]; }
+    acc &= (1 << nbits) - 1;
+  }
+  if (nbits > 0) out += B32[(acc << (5 - nbits)) & 31];
+  return out;
+}
+function cborHead(major, n) {
+  if (n < 24) return Buffer.from([(major << 5) | n]);
+  if (n < 256) return Buffer.from([(major << 5) | 24, n]);
+  if (n < 65536) return Buffer.from([(major << 5) | 25, n >> 8, n & 0xff]);
+  return Buffer.from([(major << 5) | 26, (n >>> 24) & 0xff, (n >>> 16) & 0xff, (n >>> 8) & 0xff, n & 0xff]);
+}
+const cborText = (t) => { const b = Buffer.from(t, "utf-8"); return Buffer.concat([cborHead(3, b.length), b]); };
+const cborBytes = (b) => Buffer.concat([cborHead(2, b.length), b]);
+const cborU32 = (v) => Buffer.from([0x1a, (v >>> 24) & 0xff, (v >>> 16) & 0xff, (v >>> 8) & 0xff, v & 0xff]);
+
+function syntheticPass(opts) {
+  const o = Object.assign({ format: "live", givenName: "Jack", familyName: "Sparrow", dob: "1960-04-16",
+                            nbf: 1635883530, exp: 1951416330 }, opts || {});
+  const live = o.format === "live";
+  const iss = o.iss || (live ? "did:web:nzcp.identity.health.nz" : "did:web:nzcp.covid19.health.nz");
+  const kid = o.kid || (live ? Buffer.from("z12Kf7UQ", "ascii") : Buffer.from("key-1", "ascii"));
+  const cti = o.cti || crypto.createHash("sha256").update(`${o.givenName}|${o.familyName}|${o.dob}`).digest().slice(0, 16);
+  const signature = o.signature || crypto.createHash("sha512").update(cti).digest();
+  const protectedHdr = Buffer.concat([Buffer.from([0xa2, 0x04]), cborBytes(kid), Buffer.from([0x01, 0x26])]);
+  const subj = Buffer.concat([Buffer.from([0xa3]), cborText("givenName"), cborText(o.givenName), cborText("familyName"),
+                              cborText(o.familyName), cborText("dob"), cborText(o.dob)]);
+  const vc = Buffer.concat([Buffer.from([0xa4]), cborText("@context"), Buffer.from([0x82]),
+                            cborText("https://www.w3.org/2018/credentials/v1"), cborText("https://nzcp.covid19.health.nz/contexts/v1"),
+                            cborText("version"), cborText("1.0.0"), cborText("type"), Buffer.from([0x82]),
+                            cborText("VerifiableCredential"), cborText("PublicCovidPass"), cborText("credentialSubject"), subj]);
+  const payload = Buffer.concat([Buffer.from([0xa5, 0x01]), cborText(iss), Buffer.from([0x05]), cborU32(o.nbf), Buffer.from([0x04]),
+                                 cborU32(o.exp), cborText("vc"), vc, Buffer.from([0x07]), cborBytes(cti)]);
+  const cose = Buffer.concat([Buffer.from([0xd2, 0x84]), cborBytes(protectedHdr), Buffer.from([0xa0]), cborBytes(payload),
+                              cborBytes(signature)]);
+  return "NZCP:/1/" + base32Encode(cose);
+}
+
+// Byte offsets inside ToBeSigned of the three credential strings and of the 4 exp bytes: the circuit constants
+// of the fixed-layout NZCP interface circuit (g16_nzcp_fixed_layout_setup); also the offsets the reference's
+// tests name (claims map, exp, vc, credentialSubject).
+function fixedLayout(uri) {
+  const tbs = toBeSigned(uri);
+  const find = (needle, from) => { const i = tbs.indexOf(needle, from || 0); if (i < 0) throw new Error("layout: key not found"); return i; };
+  const textAt = (pos) => {   // CBOR text string header at pos -> [offset of the characters, length]
+    const r = new Cbor(tbs); r.p = pos;
+    const head = r.byte();
+    if (head >> 5 !== 3) throw new Error("layout: expected a text string");
+    const len = r.arg(head & 31);
+    return [r.p, len];
+  };
+  const { payload } = parsePassURI(uri);
+  const claimsAt = tbs.length - payload.length;
+  const subjKey = find(cborText("credentialSubject"));
+  const given = textAt(find(cborText("givenName"), subjKey) + 10);
+  const family = textAt(find(cborText("familyName"), subjKey) + 11);
+  const dob = textAt(find(cborText("dob"), subjKey) + 4);
+  // claim 4 (exp): walk the top-level claims map
+  const r = new Cbor(tbs); r.p = claimsAt;
+  const head = r.byte();
+  if (head >> 5 !== 5) throw new Error("layout: claims are not a map");
+  let expOff = -1;
+  for (let i = 0, n = r.arg(head & 31); i < n; i++) {
+    const k = r.item();
+    if (k === 4) { if (tbs[r.p] !== 0x1a) throw new Error("layout: exp is not a 32-bit uint"); expOff = r.p + 1; }
+    r.item();
+  }
+  if (expOff < 0) throw new Error("layout: no exp claim");
+  return { toBeSignedLen: tbs.length, claimsAt, expAt: expOff - 1, expOff, vcAt: find(cborText("vc")) + 3,
+           credSubjAt: subjKey + 18, segs: [given, family, dob] };
+}
+
+module.exports = { base32Decode, base32Encode, parsePassURI, toBeSigned, circuitInput, claims, expectedPublicSignals,
+                   publicSignalsMatchPass, syntheticPass, fixedLayout };

@@ -145,3 +145,64 @@ def test_node_prove_of_example_pass_matches_the_pass(addon, amd, tmp_path):
     assert r.returncode == 0, r.stderr
     o = json.loads(r.stdout)
     assert o == {"ok": True, "n": 513, "last": str(example_public_signals()[512]), "protocol": "groth16", "curve": "bn128"}
+
+
+@needs_node
+def test_synthetic_pass_generator_reproduces_the_example_and_the_live_offsets():
+    """syntheticPass: with the example's cti and signature it must reproduce the MoH example URI
+    byte for byte (/root/reference/test/nzcp.js:51); in live format the claims map / exp / vc / credentialSubject
+    sit at 30 / 72 / 80 / 250 of ToBeSigned (/root/reference/circuits/nzcptpl.circom:438,
+    /root/reference/test/nzcp.js:103,158,230), the example's at 27 / 68 / 76 / 246."""
+    uri = open(golden_path("example_pass_uri.txt")).read().strip()
+    script = f"""
+    const n = require({json.dumps(os.path.join(JS, "nzcpInput.js"))});
+    const ex = {json.dumps(uri)};
+    const same = n.syntheticPass({{format: "example", cti: Buffer.from("60a4f54d4e304332be33ad78b1eafa4b", "hex"),
+                                  signature: n.parsePassURI(ex).signature}});
+    const live = n.syntheticPass({{givenName: "Aroha", familyName: "Ngata-Smith", dob: "1987-11-02", exp: 1767225600}});
+    console.log(JSON.stringify({{same: same === ex, exl: n.fixedLayout(ex), livel: n.fixedLayout(live), c: n.claims(live),
+                                pub: n.expectedPublicSignals(live).length, again: n.syntheticPass({{givenName: "Aroha",
+                                familyName: "Ngata-Smith", dob: "1987-11-02", exp: 1767225600}}) === live}}));
+    """
+    r = run_node(script)
+    assert r.returncode == 0, r.stderr
+    o = json.loads(r.stdout)
+    assert o["same"] and o["again"] and o["pub"] == 513
+    ex, lv = o["exl"], o["livel"]
+    assert (ex["claimsAt"], ex["expAt"], ex["vcAt"], ex["credSubjAt"], ex["toBeSignedLen"]) == (27, 68, 76, 246, 314)
+    assert ex["segs"] == [[258, 4], [274, 7], [286, 10]]
+    assert (lv["claimsAt"], lv["expAt"], lv["vcAt"], lv["credSubjAt"]) == (30, 72, 80, 250)
+    assert lv["toBeSignedLen"] <= 355
+    assert o["c"] == {"exp": 1767225600, "nbf": 1635883530, "iss": "did:web:nzcp.identity.health.nz",
+                      "givenName": "Aroha", "familyName": "Ngata-Smith", "dob": "1987-11-02"}
+
+
+@needs_node
+@pytest.mark.gpu
+def test_node_prove_of_a_synthetic_live_format_pass(addon, amd, tmp_path):
+    """config 2's public interface on a live-FORMAT pass: generate the pass, derive the circuit constants with
+    fixedLayout, key the fixed-layout circuit, prove through the N-API addon, check public.json against the pass."""
+    gen = f"""
+    const n = require({json.dumps(os.path.join(JS, "nzcpInput.js"))});
+    const uri = n.syntheticPass({{givenName: "Hemi", familyName: "Walker", dob: "2001-02-28", exp: 1798761600}});
+    console.log(JSON.stringify({{uri, tbs: n.toBeSigned(uri).toString("hex"), lay: n.fixedLayout(uri)}}));
+    """
+    r = run_node(gen)
+    assert r.returncode == 0, r.stderr
+    g0 = json.loads(r.stdout)
+    tbs, lay = bytes.fromhex(g0["tbs"]), g0["lay"]
+    out = amd.nzcp_fixed_layout_setup(tbs, [tuple(x) for x in lay["segs"]], lay["expOff"], 20260101)
+    zk, wt = tmp_path / "live.zkey", tmp_path / "live.wtns"
+    zk.write_bytes(out["zkey"])
+    wt.write_bytes(out["wtns"])
+    script = f"""
+    const {{ groth16 }} = require({json.dumps(JS)});
+    const nz = require({json.dumps(os.path.join(JS, "nzcpInput.js"))});
+    (async () => {{
+      const {{ publicSignals }} = await groth16.prove({json.dumps(str(zk))}, {json.dumps(str(wt))});
+      console.log(JSON.stringify({{ok: nz.publicSignalsMatchPass(publicSignals, {json.dumps(g0["uri"])}), exp: publicSignals[512]}}));
+    }})();
+    """
+    r = run_node(script)
+    assert r.returncode == 0, r.stderr
+    assert json.loads(r.stdout) == {"ok": True, "exp": "1798761600"}
