@@ -97,3 +97,53 @@ def test_fft_sizes_one_and_two(amd):
         assert [int.from_bytes(out[i * 32:(i + 1) * 32], "little") * rinv % b.R for i in range(n)] == g.ntt(vals)
         back = amd.fr_fft(out, inverse=True)
         assert back == mont
+
+
+def test_random_shapes_and_tuning_knobs(amd):
+    """24 seeded random combinations of circuit shape, window bits, task length and precomputation factor:
+    every proof must equal the big-int oracle's."""
+    rng = random.Random(20260103)
+    for case in range(24):
+        n = rng.choice([7, 33, 120, 257, 600])
+        p = rng.choice([0, 1, 5, min(n - 2, 40)])
+        m = rng.choice([1, 9, 64, 200, 500])
+        c = rng.choice([0, 0, 2, 5, 8, 11, 13, 16])
+        tl = rng.choice([0, 0, 1, 3, 16, 500])
+        pf = rng.choice([0, 0, 2, 4, 7])
+        seed = 5000 + case
+        zkb, wt, _ = amd.synth_setup(n, p, m, seed)
+        w = f.read_wtns(wt)["w"]
+        r, s = rng.randrange(b.R), rng.randrange(b.R)
+        _prove_both(amd, zkb, w, r, s, window_bits=c, task_len=tl, precomp=pf)
+
+
+def test_two_handles_prove_concurrently_from_two_threads(amd):
+    """Two resident keys on one GPU, proved at the same time from two host threads (what Node's worker pool
+    does with two createProver handles): both results equal their single-threaded proofs."""
+    import threading
+    zk1, wt1, _ = amd.synth_setup(3000, 513, 2500, 71)
+    zk2, wt2, _ = amd.synth_setup(1800, 7, 3000, 72)
+    p1, p2 = amd.Prover(zk1), amd.Prover(zk2)
+    r, s = f.le(12345), f.le(67890)
+    want1, want2 = p1.prove(wt1, r, s), p2.prove(wt2, r, s)
+    got, errs = {}, []
+
+    def work(key, prover, wt):
+        try:
+            for _ in range(6):
+                res = prover.prove(wt, r, s)
+                if key in got:
+                    assert got[key] == res
+                got[key] = res
+        except Exception as e:  # surfaced below
+            errs.append(e)
+
+    ts = [threading.Thread(target=work, args=(1, p1, wt1)), threading.Thread(target=work, args=(2, p2, wt2))]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert not errs, errs
+    assert got[1] == want1 and got[2] == want2
+    p1.close()
+    p2.close()
