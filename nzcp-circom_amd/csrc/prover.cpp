@@ -542,13 +542,13 @@ static int launch_ctx(g16_prover* P, ProofCtx& c, const Fr* d_w) {
   th("qap+ntt");
   static const int order[4] = {2, 3, 0, 1};   // longest chains first: B2 (G2), C, A, B1
   // experiment knobs: G16_GATE = 5 digits (A,B1,B2,C,H): 1 = that MSM's accumulate waits for the NTT chain,
-  // 2 = for the H-MSM's sort (the H-MSM is then enqueued first);
+  // 2 = for the H-MSM's sort (the H-MSM is then enqueued first), 3 = the WHOLE MSM starts after the H-MSM's sort;
   // G16_ACC_WAVES = 5 digits: wavefronts per SIMD of the persistent accumulate grid (0 = full)
   static const char* gate_s = getenv("G16_GATE");
   static const char* occ_s = getenv("G16_ACC_WAVES");
   static const bool chain = getenv("G16_CHAIN") != nullptr;
   bool h_first = false;
-  for (int i = 0; i < 4; i++) h_first |= gate_s && strlen(gate_s) == 5 && gate_s[i] == '2';
+  for (int i = 0; i < 4; i++) h_first |= gate_s && strlen(gate_s) == 5 && (gate_s[i] == '2' || gate_s[i] == '3');
   auto launch_h = [&]() -> int {
     msm_set_schedule(c.ws[4], nullptr, (occ_s && strlen(occ_s) == 5) ? (uint32_t)(occ_s[4] - '0') : 0);
     G16_HIP(hipEventRecord(c.mev[4][0], c.st));
@@ -566,6 +566,7 @@ static int launch_ctx(g16_prover* P, ProofCtx& c, const Fr* d_w) {
     if (chain && oi > 0) gate = msm_accum_done_event(c.ws[order[oi - 1]]);   // one witness accumulate at a time
     msm_set_schedule(c.ws[i], gate, occ);
     if (c.mst[i] != c.st) G16_HIP(hipStreamWaitEvent(c.mst[i], c.ev[2], 0));
+    if (g == '3' && c.mst[i] != c.st) G16_HIP(hipStreamWaitEvent(c.mst[i], msm_sorted_event(c.ws[4]), 0));   // whole MSM after the H sort
     G16_HIP(hipEventRecord(c.mev[i][0], c.mst[i]));
     if ((rc = msm_launch(P->msm[i], c.ws[i], d_w, c.mst[i]))) return rc;
     G16_HIP(hipEventRecord(c.mev[i][1], c.mst[i]));
