@@ -134,3 +134,21 @@ def test_r1cs_reader_errors(amd):
     bad[secs[1][0][0] + 4] ^= 1      # another prime
     with pytest.raises(amd.G16Error, match="not the bn128 scalar field"):
         amd.r1cs_setup(bytes(bad), 1)
+
+
+def test_nzcp_fixed_circuit_tool(tmp_path):
+    """tools/nzcp_fixed_circuit.py (host only): artefacts for snarkjs cross-checks from the example pass URI."""
+    import subprocess
+    import sys
+    from conftest import ROOT, golden_path
+    out = tmp_path / "fx"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "nzcp_fixed_circuit.py"),
+                        golden_path("example_pass_uri.txt"), str(out)], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr
+    assert "Jack,Sparrow,1960-04-16" in r.stdout and "exp 1951416330" in r.stdout
+    exp = json.load(open(out / "expected_public.json"))
+    assert len(exp) == 513 and exp[512] == "1951416330"
+    assert "".join(exp[256:512]) == bin(int("271ce33d671a2d3b816d788135f4343e14bc66802f8cd841faac939e8c11f3ee", 16))[2:].zfill(256)
+    vk = json.load(open(out / "verification_key.json"))
+    assert vk["nPublic"] == 513 and len(vk["IC"]) == 514 and vk["protocol"] == "groth16"
+    assert (out / "circuit.r1cs").read_bytes()[:4] == b"r1cs" and (out / "circuit.zkey").read_bytes()[:4] == b"zkey"
