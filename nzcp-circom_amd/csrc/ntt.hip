@@ -75,8 +75,17 @@ __global__ __launch_bounds__(kThreads) void ntt_pass_kernel(VecPtrs vecs, const 
     for (uint32_t bf = threadIdx.x; bf < (tile_n >> 1); bf += kThreads) {
       const uint32_t e0 = ((bf >> bit) << (bit + 1)) | (bf & ((1u << bit) - 1));
       const uint32_t e1 = e0 | (1u << bit);
-      const F29 w = tw[(gidx(e0) & hmask) << sh];
       const F29 u = tile[e0], v = tile[e1];
+      if (beta == 0) {
+        // the stage on global index bit 0: every twiddle is w^0 = 1, no product (1/21 of all butterflies at 2^21).
+        // DIF: it is the last stage, d < 16r goes to the store / the coset product; DIT: it is the first stage,
+        // v was weak-reduced on load (< 1.0001 r), so sub<2> covers it.
+        tile[e0] = fr29_add(u, v);
+        tile[e1] = dif ? (phase == 0 ? fr29_sub<2>(u, v) : (phase == 1 ? fr29_sub<3>(u, v) : fr29_sub<5>(u, v)))
+                       : fr29_sub<2>(u, v);
+        continue;
+      }
+      const F29 w = tw[(gidx(e0) & hmask) << sh];
       if (dif) {
         tile[e0] = fr29_add(u, v);
         const F29 d = phase == 0 ? fr29_sub<2>(u, v) : (phase == 1 ? fr29_sub<3>(u, v) : fr29_sub<5>(u, v));
