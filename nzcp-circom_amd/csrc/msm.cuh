@@ -40,7 +40,10 @@ struct MsmWorkspace {
   uint32_t* d_off = nullptr;
   uint32_t* d_toff = nullptr;
   uint32_t* d_sorted = nullptr;
-  uint2* d_task_desc = nullptr;
+  uint2* d_task_desc = nullptr;   // by task id
+  uint4* d_qdesc = nullptr;       // by queue position: full-length tasks first (msm_task_fill_kernel)
+  uint32_t* d_foff = nullptr;     // exclusive scan of the full-length task counts, [nb] = their total
+  uint32_t* d_tile_c = nullptr;
   uint32_t* d_queue = nullptr;    // [0] work-queue head of the accumulate kernel, [1] number of flagged tasks
   uint32_t* d_redo = nullptr;     // tasks whose fast-path sum met an exceptional case (recomputed by msm_redo_kernel)
   uint32_t* d_tile_a = nullptr;
@@ -236,104 +239,124 @@ static constexpr uint32_t kScanTile = 2048;   // 256 threads x 8 counters
 
 static __global__ __launch_bounds__(256) void msm_scan_tiles_kernel(const uint32_t* __restrict__ cnt, uint32_t nb,
                                                              MsmTaskGrade tg, uint32_t* __restrict__ tile_a,
-                                                             uint32_t* __restrict__ tile_b) {
-  __shared__ uint32_t sh_a[256], sh_b[256];
+                                                             uint32_t* __restrict__ tile_b,
+                                                             uint32_t* __restrict__ tile_c) {
+  __shared__ uint32_t sh_a[256], sh_b[256], sh_c[256];
   const uint32_t tid = threadIdx.x, base = blockIdx.x * kScanTile + tid * 8;
-  uint32_t sa = 0, sb = 0;
+  uint32_t sa = 0, sb = 0, sc = 0;
 #pragma unroll
   for (int k = 0; k < 8; k++) {
     const uint32_t v = (base + k < nb) ? cnt[base + k] : 0u;
     const uint32_t tl = msm_task_len_at(tg, base + k);
     sa += v;
     sb += (v + tl - 1) / tl;
+    sc += v / tl;
   }
-  sh_a[tid] = sa; sh_b[tid] = sb;
+  sh_a[tid] = sa; sh_b[tid] = sb; sh_c[tid] = sc;
   __syncthreads();
   for (uint32_t d = 128; d > 0; d >>= 1) {
-    if (tid < d) { sh_a[tid] += sh_a[tid + d]; sh_b[tid] += sh_b[tid + d]; }
+    if (tid < d) { sh_a[tid] += sh_a[tid + d]; sh_b[tid] += sh_b[tid + d]; sh_c[tid] += sh_c[tid + d]; }
     __syncthreads();
   }
-  if (tid == 0) { tile_a[blockIdx.x] = sh_a[0]; tile_b[blockIdx.x] = sh_b[0]; }
+  if (tid == 0) { tile_a[blockIdx.x] = sh_a[0]; tile_b[blockIdx.x] = sh_b[0]; tile_c[blockIdx.x] = sh_c[0]; }
 }
 
 // ntiles <= 1024 * chunk; one workgroup; writes exclusive tile offsets in place and the totals
 static __global__ __launch_bounds__(1024) void msm_scan_top_kernel(uint32_t* __restrict__ tile_a,
-                                                            uint32_t* __restrict__ tile_b, uint32_t ntiles,
+                                                            uint32_t* __restrict__ tile_b,
+                                                            uint32_t* __restrict__ tile_c, uint32_t ntiles,
                                                             uint32_t* __restrict__ total_a,
-                                                            uint32_t* __restrict__ total_b) {
-  __shared__ uint32_t sh_a[1024], sh_b[1024];
+                                                            uint32_t* __restrict__ total_b,
+                                                            uint32_t* __restrict__ total_c) {
+  __shared__ uint32_t sh_a[1024], sh_b[1024], sh_c[1024];
   const uint32_t tid = threadIdx.x;
   const uint32_t chunk = (ntiles + 1023) / 1024;
   const uint32_t lo = tid * chunk, hi = (lo + chunk < ntiles) ? lo + chunk : ntiles;
-  uint32_t sa = 0, sb = 0;
-  for (uint32_t k = lo; k < hi; k++) { sa += tile_a[k]; sb += tile_b[k]; }
-  sh_a[tid] = sa; sh_b[tid] = sb;
+  uint32_t sa = 0, sb = 0, sc = 0;
+  for (uint32_t k = lo; k < hi; k++) { sa += tile_a[k]; sb += tile_b[k]; sc += tile_c[k]; }
+  sh_a[tid] = sa; sh_b[tid] = sb; sh_c[tid] = sc;
   __syncthreads();
   for (uint32_t d = 1; d < 1024; d <<= 1) {
-    uint32_t va = 0, vb = 0;
-    if (tid >= d) { va = sh_a[tid - d]; vb = sh_b[tid - d]; }
+    uint32_t va = 0, vb = 0, vc = 0;
+    if (tid >= d) { va = sh_a[tid - d]; vb = sh_b[tid - d]; vc = sh_c[tid - d]; }
     __syncthreads();
-    sh_a[tid] += va; sh_b[tid] += vb;
+    sh_a[tid] += va; sh_b[tid] += vb; sh_c[tid] += vc;
     __syncthreads();
   }
-  uint32_t pa = sh_a[tid] - sa, pb = sh_b[tid] - sb;
+  uint32_t pa = sh_a[tid] - sa, pb = sh_b[tid] - sb, pc = sh_c[tid] - sc;
   for (uint32_t k = lo; k < hi; k++) {
-    const uint32_t va = tile_a[k], vb = tile_b[k];
-    tile_a[k] = pa; tile_b[k] = pb;
-    pa += va; pb += vb;
+    const uint32_t va = tile_a[k], vb = tile_b[k], vc = tile_c[k];
+    tile_a[k] = pa; tile_b[k] = pb; tile_c[k] = pc;
+    pa += va; pb += vb; pc += vc;
   }
-  if (tid == 1023) { *total_a = sh_a[1023]; *total_b = sh_b[1023]; }
+  if (tid == 1023) { *total_a = sh_a[1023]; *total_b = sh_b[1023]; *total_c = sh_c[1023]; }
 }
 
 static __global__ __launch_bounds__(256) void msm_scan_apply_kernel(const uint32_t* __restrict__ cnt, uint32_t nb,
                                                              MsmTaskGrade tg,
                                                              const uint32_t* __restrict__ tile_a,
                                                              const uint32_t* __restrict__ tile_b,
+                                                             const uint32_t* __restrict__ tile_c,
                                                              uint32_t* __restrict__ off,
-                                                             uint32_t* __restrict__ toff) {
-  __shared__ uint32_t sh_a[256], sh_b[256];
+                                                             uint32_t* __restrict__ toff,
+                                                             uint32_t* __restrict__ foff) {
+  __shared__ uint32_t sh_a[256], sh_b[256], sh_c[256];
   const uint32_t tid = threadIdx.x, base = blockIdx.x * kScanTile + tid * 8;
-  uint32_t v[8], sa = 0, sb = 0;
+  uint32_t v[8], sa = 0, sb = 0, sc = 0;
 #pragma unroll
   for (int k = 0; k < 8; k++) {
     v[k] = (base + k < nb) ? cnt[base + k] : 0u;
     const uint32_t tl = msm_task_len_at(tg, base + k);
     sa += v[k];
     sb += (v[k] + tl - 1) / tl;
+    sc += v[k] / tl;
   }
-  sh_a[tid] = sa; sh_b[tid] = sb;
+  sh_a[tid] = sa; sh_b[tid] = sb; sh_c[tid] = sc;
   __syncthreads();
   for (uint32_t d = 1; d < 256; d <<= 1) {
-    uint32_t va = 0, vb = 0;
-    if (tid >= d) { va = sh_a[tid - d]; vb = sh_b[tid - d]; }
+    uint32_t va = 0, vb = 0, vc = 0;
+    if (tid >= d) { va = sh_a[tid - d]; vb = sh_b[tid - d]; vc = sh_c[tid - d]; }
     __syncthreads();
-    sh_a[tid] += va; sh_b[tid] += vb;
+    sh_a[tid] += va; sh_b[tid] += vb; sh_c[tid] += vc;
     __syncthreads();
   }
-  uint32_t pa = tile_a[blockIdx.x] + sh_a[tid] - sa, pb = tile_b[blockIdx.x] + sh_b[tid] - sb;
+  uint32_t pa = tile_a[blockIdx.x] + sh_a[tid] - sa, pb = tile_b[blockIdx.x] + sh_b[tid] - sb,
+           pc = tile_c[blockIdx.x] + sh_c[tid] - sc;
 #pragma unroll
   for (int k = 0; k < 8; k++) {
     if (base + k < nb) {
       off[base + k] = pa;
       toff[base + k] = pb;
+      foff[base + k] = pc;
     }
     pa += v[k];
     const uint32_t tl = msm_task_len_at(tg, base + k);
     pb += (v[k] + tl - 1) / tl;
+    pc += v[k] / tl;
   }
 }
 
-// task descriptor = (first sorted entry, entry count); tasks of one bucket are consecutive
+// task descriptor = (first sorted entry, entry count); the tasks of one bucket have consecutive ids (their
+// partial sums are consecutive for the combine pass).  The work QUEUE is a permutation of the tasks: every
+// full-length task first, the remainders (one per bucket at most, shorter) after them -- the 64 lanes of a
+// wavefront then start and finish their full tasks in the same iteration, so the flush / start / request code
+// of the accumulate loop runs once per task instead of in nearly every iteration, and the queue ends with its
+// shortest tasks (a shorter drain).  qdesc[q] = (first entry, count, task id, -).
 static __global__ __launch_bounds__(256) void msm_task_fill_kernel(const uint32_t* __restrict__ off,
-                                                            const uint32_t* __restrict__ toff, uint32_t nb,
-                                                            MsmTaskGrade tg, uint2* __restrict__ task_desc) {
+                                                            const uint32_t* __restrict__ toff,
+                                                            const uint32_t* __restrict__ foff, uint32_t nb,
+                                                            MsmTaskGrade tg, uint2* __restrict__ task_desc,
+                                                            uint4* __restrict__ qdesc) {
   const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= nb) return;
   const uint32_t task_len = msm_task_len_at(tg, b);
   uint32_t start = off[b], left = off[b + 1] - start;
+  uint32_t fq = foff[b];
+  const uint32_t rq = foff[nb] + (toff[b] - foff[b]);   // remainders: after all the full tasks, in bucket order
   for (uint32_t t = toff[b], e = toff[b + 1]; t < e; t++) {
     const uint32_t len = left < task_len ? left : task_len;
     task_desc[t] = make_uint2(start, len);
+    qdesc[len == task_len ? fq++ : rq] = make_uint4(start, len, t, 0u);
     start += len;
     left -= len;
   }
@@ -354,7 +377,7 @@ template <class F>
 __global__ __launch_bounds__(64, F::kAccumWavesPerSimd) void msm_accumulate_kernel(const PackedAffine<F>* __restrict__ bases,
                                                             const uint32_t* __restrict__ sorted,
                                                             const uint32_t* __restrict__ toff, uint32_t nb,
-                                                            const uint2* __restrict__ task_desc,
+                                                            const uint4* __restrict__ qdesc,
                                                             uint32_t* __restrict__ queue,
                                                             uint32_t* __restrict__ redo,
                                                             XYZZ<F>* __restrict__ partial) {
@@ -366,7 +389,7 @@ __global__ __launch_bounds__(64, F::kAccumWavesPerSimd) void msm_accumulate_kern
   bool exhausted = false;               // wave-uniform: the queue has no more chunks
   uint32_t my_task = kNone, pending = kNone, cur = 0, end = 0;
   bool bad = false;                     // the running task met an exceptional case: its sum is redone
-  uint2 desc = make_uint2(0, 0);
+  uint4 desc = make_uint4(0, 0, 0, 0);
   XYZZ<F> acc;
   x29_set_inf(acc);
   // (Staggering the wavefronts of a SIMD by HW_ID.WAVE_ID so that their gathers do not coincide was measured:
@@ -380,7 +403,7 @@ __global__ __launch_bounds__(64, F::kAccumWavesPerSimd) void msm_accumulate_kern
     }
     // 2. idle lanes whose next descriptor has arrived start it: the first entry IS the accumulator
     if (my_task == kNone && pending != kNone) {
-      my_task = pending;
+      my_task = desc.z;     // the task id (where its partial sum goes); `pending` was its queue position
       pending = kNone;
       cur = desc.x;
       end = desc.x + desc.y;
@@ -411,7 +434,7 @@ __global__ __launch_bounds__(64, F::kAccumWavesPerSimd) void msm_accumulate_kern
           const uint32_t cand = next + (uint32_t)__popcll(m & lt_mask);
           if (cand < chunk_end) {
             pending = cand;
-            desc = task_desc[cand];
+            desc = qdesc[cand];
           }
         }
         next += (uint32_t)__popcll(m);
@@ -674,15 +697,17 @@ int msm_launch_t(const MsmInstance& m, MsmWorkspace* ws, const Fr* d_scalars, hi
   msm_hist_sum_kernel<<<(nb + 255) / 256, 256, 0, st>>>(ws->d_hist, nb, B, chunks, ws->d_cnt);
   const uint32_t ntiles = (nb + kScanTile - 1) / kScanTile;
   const MsmTaskGrade tg = msm_task_grade(m.task_len, W, B);
-  msm_scan_tiles_kernel<<<ntiles, 256, 0, st>>>(ws->d_cnt, nb, tg, ws->d_tile_a, ws->d_tile_b);
-  msm_scan_top_kernel<<<1, 1024, 0, st>>>(ws->d_tile_a, ws->d_tile_b, ntiles, ws->d_off + nb, ws->d_toff + nb);
-  msm_scan_apply_kernel<<<ntiles, 256, 0, st>>>(ws->d_cnt, nb, tg, ws->d_tile_a, ws->d_tile_b, ws->d_off,
-                                                ws->d_toff);
+  msm_scan_tiles_kernel<<<ntiles, 256, 0, st>>>(ws->d_cnt, nb, tg, ws->d_tile_a, ws->d_tile_b, ws->d_tile_c);
+  msm_scan_top_kernel<<<1, 1024, 0, st>>>(ws->d_tile_a, ws->d_tile_b, ws->d_tile_c, ntiles, ws->d_off + nb, ws->d_toff + nb,
+                                          ws->d_foff + nb);
+  msm_scan_apply_kernel<<<ntiles, 256, 0, st>>>(ws->d_cnt, nb, tg, ws->d_tile_a, ws->d_tile_b, ws->d_tile_c, ws->d_off,
+                                                ws->d_toff, ws->d_foff);
   msm_hist_start_kernel<<<(nb + 255) / 256, 256, 0, st>>>(ws->d_hist, nb, B, chunks, ws->d_off);
   mark(2);
   msm_sort_kernel<1><<<WT * chunks, 1024, lds_bytes, st>>>(ws->d_dig, ne, B, chunks, per, ws->d_hist, ws->d_sorted);
   mark(3);
-  msm_task_fill_kernel<<<(nb + 255) / 256, 256, 0, st>>>(ws->d_off, ws->d_toff, nb, tg, ws->d_task_desc);
+  msm_task_fill_kernel<<<(nb + 255) / 256, 256, 0, st>>>(ws->d_off, ws->d_toff, ws->d_foff, nb, tg, ws->d_task_desc,
+                                                         ws->d_qdesc);
   // upper bound on tasks: every non-empty bucket has <= 1 short task + entries/task_len full ones
   // (the shortest graded tasks hold task_len / 4 >= 4 entries; ones: <= n entries, covered)
   const uint64_t max_tasks = (uint64_t)nb + ((uint64_t)m.n * (uint32_t)m.Ws) / (m.task_len >= 16 ? m.task_len / 4 : 4);
@@ -698,7 +723,7 @@ int msm_launch_t(const MsmInstance& m, MsmWorkspace* ws, const Fr* d_scalars, hi
   if (ws->accum_gate) G16_HIP(hipStreamWaitEvent(st, ws->accum_gate, 0));
   G16_HIP(hipEventRecord(ws->ev0, st));
   msm_accumulate_kernel<F><<<(unsigned)waves, 64, 0, st>>>((const PackedAffine<F>*)m.d_bases, ws->d_sorted, ws->d_toff, nb,
-                                                            ws->d_task_desc, ws->d_queue, ws->d_redo, (PT*)ws->d_partial);
+                                                            ws->d_qdesc, ws->d_queue, ws->d_redo, (PT*)ws->d_partial);
   G16_HIP(hipEventRecord(ws->ev1, st));
   msm_redo_kernel<F><<<64, 64, 0, st>>>((const PackedAffine<F>*)m.d_bases, ws->d_sorted, ws->d_task_desc, ws->d_queue,
                                         ws->d_redo, (PT*)ws->d_partial);
