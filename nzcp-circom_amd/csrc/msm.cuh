@@ -444,8 +444,9 @@ __global__ __launch_bounds__(64, F::kAccumWavesPerSimd) void msm_accumulate_kern
     // 4. done when no lane holds or awaits a task and the queue is empty
     if (exhausted && __ballot(my_task != kNone || pending != kNone) == 0) break;
     // 5. one mixed addition per lane that has entries left.  (Requesting the NEXT point before this addition --
-    //    software prefetch, 18 more VGPRs -- was measured and gains nothing: four wavefronts per SIMD already
-    //    hide the two dependent loads.)
+    //    software prefetch, 18 more VGPRs -- was measured twice, before and after the queue was ordered (two-stage
+    //    pipeline of packed point + next index): 2.77 -> 2.89 ms on the H-MSM.  Four wavefronts per SIMD already
+    //    hide the two dependent loads; the extra moves and registers only cost issue slots.)
     if (my_task != kNone && cur != end) {
       const uint32_t idx = sorted[cur++];
       Affine<F> p;
