@@ -44,6 +44,7 @@ struct MsmWorkspace {
   uint4* d_qdesc = nullptr;       // by queue position: full-length tasks first (msm_task_fill_kernel)
   uint32_t* d_foff = nullptr;     // exclusive scan of the full-length task counts, [nb] = their total
   uint32_t* d_tile_c = nullptr;
+  uint32_t* d_class = nullptr;    // [2][kRemClasses]: remainder-class totals and cursors
   uint32_t* d_queue = nullptr;    // [0] work-queue head of the accumulate kernel, [1] number of flagged tasks
   uint32_t* d_redo = nullptr;     // tasks whose fast-path sum met an exceptional case (recomputed by msm_redo_kernel)
   uint32_t* d_tile_a = nullptr;
@@ -342,21 +343,64 @@ static __global__ __launch_bounds__(256) void msm_scan_apply_kernel(const uint32
 // wavefront then start and finish their full tasks in the same iteration, so the flush / start / request code
 // of the accumulate loop runs once per task instead of in nearly every iteration, and the queue ends with its
 // shortest tasks (a shorter drain).  qdesc[q] = (first entry, count, task id, -).
+static constexpr uint32_t kRemClasses = 32;   // remainder tasks are queued by relative length, longest class first
+__device__ __forceinline__ uint32_t msm_rem_class(uint32_t len, uint32_t task_len) {
+  return (len * kRemClasses) / task_len;      // len < task_len -> 0 .. kRemClasses - 1
+}
+
+// class_total[c] = number of remainder tasks (cnt % task_len != 0) of relative-length class c
+static __global__ __launch_bounds__(256) void msm_rem_count_kernel(const uint32_t* __restrict__ cnt, uint32_t nb,
+                                                            MsmTaskGrade tg, uint32_t* __restrict__ class_total) {
+  __shared__ uint32_t h[kRemClasses];
+  if (threadIdx.x < kRemClasses) h[threadIdx.x] = 0;
+  __syncthreads();
+  const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b < nb) {
+    const uint32_t tl = msm_task_len_at(tg, b), r = cnt[b] % tl;
+    if (r) atomicAdd(&h[msm_rem_class(r, tl)], 1u);
+  }
+  __syncthreads();
+  if (threadIdx.x < kRemClasses && h[threadIdx.x]) atomicAdd(&class_total[threadIdx.x], h[threadIdx.x]);
+}
+
 static __global__ __launch_bounds__(256) void msm_task_fill_kernel(const uint32_t* __restrict__ off,
                                                             const uint32_t* __restrict__ toff,
                                                             const uint32_t* __restrict__ foff, uint32_t nb,
                                                             MsmTaskGrade tg, uint2* __restrict__ task_desc,
-                                                            uint4* __restrict__ qdesc) {
+                                                            uint4* __restrict__ qdesc,
+                                                            const uint32_t* __restrict__ class_total,
+                                                            uint32_t* __restrict__ class_cursor) {
+  // remainders: after all the full tasks, by relative-length class (longest first) so that the lanes of a
+  // wavefront hold remainders of (nearly) equal length; inside a class the order is whatever the atomics give
+  __shared__ uint32_t h[kRemClasses], base[kRemClasses];
+  if (threadIdx.x < kRemClasses) h[threadIdx.x] = 0;
+  __syncthreads();
   const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+  uint32_t task_len = 1, start = 0, left = 0, rem = 0, cls = 0, rank = 0;
+  if (b < nb) {
+    task_len = msm_task_len_at(tg, b);
+    start = off[b];
+    left = off[b + 1] - start;
+    rem = left % task_len;
+    if (rem) {
+      cls = msm_rem_class(rem, task_len);
+      rank = atomicAdd(&h[cls], 1u);
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x < kRemClasses) {
+    const uint32_t c = threadIdx.x;
+    uint32_t before = foff[nb];                              // all full tasks, then the longer classes
+    for (uint32_t k = c + 1; k < kRemClasses; k++) before += class_total[k];
+    base[c] = h[c] ? before + atomicAdd(&class_cursor[c], h[c]) : 0u;
+  }
+  __syncthreads();
   if (b >= nb) return;
-  const uint32_t task_len = msm_task_len_at(tg, b);
-  uint32_t start = off[b], left = off[b + 1] - start;
   uint32_t fq = foff[b];
-  const uint32_t rq = foff[nb] + (toff[b] - foff[b]);   // remainders: after all the full tasks, in bucket order
   for (uint32_t t = toff[b], e = toff[b + 1]; t < e; t++) {
     const uint32_t len = left < task_len ? left : task_len;
     task_desc[t] = make_uint2(start, len);
-    qdesc[len == task_len ? fq++ : rq] = make_uint4(start, len, t, 0u);
+    qdesc[len == task_len ? fq++ : base[cls] + rank] = make_uint4(start, len, t, 0u);
     start += len;
     left -= len;
   }
@@ -707,8 +751,10 @@ int msm_launch_t(const MsmInstance& m, MsmWorkspace* ws, const Fr* d_scalars, hi
   mark(2);
   msm_sort_kernel<1><<<WT * chunks, 1024, lds_bytes, st>>>(ws->d_dig, ne, B, chunks, per, ws->d_hist, ws->d_sorted);
   mark(3);
+  G16_HIP(hipMemsetAsync(ws->d_class, 0, 2 * 32 * 4, st));
+  msm_rem_count_kernel<<<(nb + 255) / 256, 256, 0, st>>>(ws->d_cnt, nb, tg, ws->d_class);
   msm_task_fill_kernel<<<(nb + 255) / 256, 256, 0, st>>>(ws->d_off, ws->d_toff, ws->d_foff, nb, tg, ws->d_task_desc,
-                                                         ws->d_qdesc);
+                                                         ws->d_qdesc, ws->d_class, ws->d_class + 32);
   // upper bound on tasks: every non-empty bucket has <= 1 short task + entries/task_len full ones
   // (the shortest graded tasks hold task_len / 4 >= 4 entries; ones: <= n entries, covered)
   const uint64_t max_tasks = (uint64_t)nb + ((uint64_t)m.n * (uint32_t)m.Ws) / (m.task_len >= 16 ? m.task_len / 4 : 4);

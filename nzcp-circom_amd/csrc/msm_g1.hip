@@ -179,6 +179,7 @@ int msm_workspace_create(MsmWorkspace** out, const MsmInstance* insts, int ninst
   G16_HIP(hipMalloc(&ws->d_qdesc, ((size_t)ws->max_tasks + 1) * sizeof(uint4)));
   G16_HIP(hipMalloc(&ws->d_foff, ((size_t)ws->max_buckets + 1) * 4));
   G16_HIP(hipMalloc(&ws->d_tile_c, ((size_t)ws->max_buckets / kScanTile + 2) * 4));
+  G16_HIP(hipMalloc(&ws->d_class, 2 * 32 * 4));
   G16_HIP(hipMalloc(&ws->d_queue, 64));
   G16_HIP(hipMalloc(&ws->d_redo, ((size_t)ws->max_tasks + 1) * 4));
   G16_HIP(hipMalloc(&ws->d_tile_a, ((size_t)ws->max_buckets / kScanTile + 2) * 4));
@@ -201,7 +202,7 @@ void msm_workspace_destroy(MsmWorkspace* ws) {
   if (!ws) return;
   void* ptrs[] = {ws->d_cnt, ws->d_off, ws->d_toff, ws->d_sorted, ws->d_task_desc, ws->d_queue, ws->d_tile_a, ws->d_tile_b,
                   ws->d_partial, ws->d_seg, ws->d_red, ws->d_bsum, ws->d_heavy, ws->d_dig, ws->d_hist, ws->d_canon, ws->d_redo,
-                  ws->d_qdesc, ws->d_foff, ws->d_tile_c};
+                  ws->d_qdesc, ws->d_foff, ws->d_tile_c, ws->d_class};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   if (ws->h_pinned) (void)hipHostFree(ws->h_pinned);
