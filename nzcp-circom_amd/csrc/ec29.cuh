@@ -97,7 +97,7 @@ template <class F> G16_HD bool x29_madd_fast(XYZZ<F>& acc, const Affine<F>& q) {
   const T PP = F::sqr(P);
   const T PPP = F::mul(P, PP);
   const T Qv = F::mul(acc.x, PP);
-  const T X3 = F::template sub<4>(F::sqr(R), F::add(PPP, F::add(Qv, Qv)));
+  const T X3 = F::sub_b_2c(F::sqr(R), PPP, Qv);   // R^2 + 4p - PPP - 2Q, one carry ripple instead of three
   acc.y = F::template sub<2>(F::mul(R, F::template sub<6>(Qv, X3)), F::mul(acc.y, PPP));
   acc.x = X3;
   acc.zz = F::mul(acc.zz, PP);

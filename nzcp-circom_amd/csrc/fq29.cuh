@@ -38,6 +38,7 @@ struct Fq29C {
   static constexpr uint32_t TO[9] = G16_FQ29_TO;
   static constexpr uint32_t FROM[9] = G16_FQ29_FROM;
   static constexpr uint32_t INV = G16_FQ29_INV;
+  static constexpr uint32_t KPX4[9] = G16_FQ29_KPX4;
   template <int K> using KP = Fq29KP<K>;
 };
 template <int K> struct Fr29KP;
@@ -53,6 +54,7 @@ struct Fr29C {
   static constexpr uint32_t TO[9] = G16_FR29_TO;
   static constexpr uint32_t FROM[9] = G16_FR29_FROM;
   static constexpr uint32_t INV = G16_FR29_INV;
+  static constexpr uint32_t KPX4[9] = G16_FR29_KPX4;
   template <int K> using KP = Fr29KP<K>;
 };
 
@@ -106,6 +108,16 @@ template <int K, class C = Fq29C> G16_HD F29 f29_sub(const F29& a, const F29& b)
   F29 r;
 #pragma unroll
   for (int i = 0; i < 9; i++) r.l[i] = a.l[i] + C::template KP<K>::V[i] - b.l[i];
+  f29_carry(r);
+  G16_F29_ASSERT_BOUND(r);
+  return r;
+}
+// a + 4p - b - 2c in one pass and one carry ripple (the X3 of the addition formulas: R^2 - PPP - 2Q); requires
+// value(b) + 2 value(c) <= 4p; the constant's limbs are inflated by 2^31 to cover limbs of b + 2c below 3 * 2^29
+template <class C = Fq29C> G16_HD F29 f29_sub_b_2c(const F29& a, const F29& b, const F29& c) {
+  F29 r;
+#pragma unroll
+  for (int i = 0; i < 9; i++) r.l[i] = a.l[i] + C::KPX4[i] - b.l[i] - 2u * c.l[i];
   f29_carry(r);
   G16_F29_ASSERT_BOUND(r);
   return r;
@@ -504,6 +516,7 @@ struct Fq29Ops {
   static G16_HD T add(const T& x, const T& y) { return f29_add(x, y); }
   template <int K> static G16_HD T sub(const T& x, const T& y) { return f29_sub<K>(x, y); }
   template <int K> static G16_HD T neg(const T& x) { return f29_neg<K>(x); }
+  static G16_HD T sub_b_2c(const T& a, const T& b, const T& c) { return f29_sub_b_2c(a, b, c); }
   static G16_HD T mul(const T& x, const T& y) { return G16_F29_MUL(x, y); }
   static G16_HD T sqr(const T& x) { return G16_F29_SQR(x); }
   static G16_HD T from_canon(const Fq& x) { return f29_from_fq(x); }
@@ -527,6 +540,9 @@ struct Fq2x29Ops {
     return T{f29_sub<K>(x.a, y.a), f29_sub<K>(x.b, y.b)};
   }
   template <int K> static G16_HD T neg(const T& x) { return T{f29_neg<K>(x.a), f29_neg<K>(x.b)}; }
+  static G16_HD T sub_b_2c(const T& a, const T& b, const T& c) {
+    return T{f29_sub_b_2c(a.a, b.a, c.a), f29_sub_b_2c(a.b, b.b, c.b)};
+  }
   // (a0 b0 - a1 b1) + (a0 b1 + a1 b0) u, two fused reductions; components of x below 8p
   static G16_HD T mul(const T& x, const T& y) {
     const F29 nb = f29_neg<8>(x.b);
