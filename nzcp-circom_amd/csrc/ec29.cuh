@@ -75,7 +75,7 @@ template <class F> G16_HD void x29_madd(XYZZ<F>& acc, const Affine<F>& q) {
   const T PP = F::sqr(P);
   const T PPP = F::mul(P, PP);
   const T Qv = F::mul(acc.x, PP);
-  const T X3 = F::template sub<4>(F::sqr(R), F::add(PPP, F::add(Qv, Qv)));
+  const T X3 = F::sub_b_2c(F::sqr(R), PPP, Qv);
   acc.y = F::template sub<2>(F::mul(R, F::template sub<6>(Qv, X3)), F::mul(acc.y, PPP));
   acc.x = X3;
   acc.zz = F::mul(acc.zz, PP);
@@ -124,7 +124,7 @@ template <class F> G16_HD void x29_add(XYZZ<F>& acc, const XYZZ<F>& q) {
   const T PP = F::sqr(P);
   const T PPP = F::mul(P, PP);
   const T Qv = F::mul(U1, PP);
-  const T X3 = F::template sub<4>(F::sqr(R), F::add(PPP, F::add(Qv, Qv)));
+  const T X3 = F::sub_b_2c(F::sqr(R), PPP, Qv);
   acc.y = F::template sub<2>(F::mul(R, F::template sub<6>(Qv, X3)), F::mul(S1, PPP));
   acc.x = X3;
   acc.zz = F::mul(F::mul(acc.zz, q.zz), PP);
