@@ -98,7 +98,13 @@ template <class F> G16_HD bool x29_madd_fast(XYZZ<F>& acc, const Affine<F>& q) {
   const T PPP = F::mul(P, PP);
   const T Qv = F::mul(acc.x, PP);
   const T X3 = F::sub_b_2c(F::sqr(R), PPP, Qv);   // R^2 + 4p - PPP - 2Q, one carry ripple instead of three
-  acc.y = F::template sub<2>(F::mul(R, F::template sub<6>(Qv, X3)), F::mul(acc.y, PPP));
+  if constexpr (F::kFusedY3) {
+    // Y1 <= 2p here (an affine coordinate, or a previous Y3 < 1.3p), so 2p - Y1 is its negative; both products
+    // share one reduction: (5.1p * 7.1p + 2p * 2.5p) / 2^261 + p < 1.3p
+    acc.y = F::mul_add(R, F::template sub<6>(Qv, X3), F::template neg<2>(acc.y), PPP);
+  } else {
+    acc.y = F::template sub<2>(F::mul(R, F::template sub<6>(Qv, X3)), F::mul(acc.y, PPP));
+  }
   acc.x = X3;
   acc.zz = F::mul(acc.zz, PP);
   acc.zzz = F::mul(acc.zzz, PPP);

@@ -517,6 +517,8 @@ struct Fq29Ops {
   template <int K> static G16_HD T sub(const T& x, const T& y) { return f29_sub<K>(x, y); }
   template <int K> static G16_HD T neg(const T& x) { return f29_neg<K>(x); }
   static G16_HD T sub_b_2c(const T& a, const T& b, const T& c) { return f29_sub_b_2c(a, b, c); }
+  static constexpr bool kFusedY3 = true;          // Y3 = R (Q - X3) + (-Y1) PPP with ONE Montgomery reduction
+  static G16_HD T mul_add(const T& a, const T& b, const T& c, const T& d) { return G16_F29_MUL2(a, b, c, d); }
   static G16_HD T mul(const T& x, const T& y) { return G16_F29_MUL(x, y); }
   static G16_HD T sqr(const T& x) { return G16_F29_SQR(x); }
   static G16_HD T from_canon(const Fq& x) { return f29_from_fq(x); }
@@ -543,6 +545,7 @@ struct Fq2x29Ops {
   static G16_HD T sub_b_2c(const T& a, const T& b, const T& c) {
     return T{f29_sub_b_2c(a.a, b.a, c.a), f29_sub_b_2c(a.b, b.b, c.b)};
   }
+  static constexpr bool kFusedY3 = false;         // would need a four-product fused reduction per component
   // (a0 b0 - a1 b1) + (a0 b1 + a1 b0) u, two fused reductions; components of x below 8p
   static G16_HD T mul(const T& x, const T& y) {
     const F29 nb = f29_neg<8>(x.b);
