@@ -382,11 +382,11 @@ def main():
                          "avg_launch_ms": round(ms_per_launch, 4),
                          "int_roofline": {
                              "kernel": "H-MSM accumulate launch (uniform 254-bit scalars)",
-                             "achieved_Tmad_per_s": round(info.n_h * 16 * 1550 / max(1e-9, acc["accum"][4] / K * 1e-3) / 1e12, 3),
+                             "achieved_Tmad_per_s": round(info.n_h * 16 * 1470 / max(1e-9, acc["accum"][4] / K * 1e-3) / 1e12, 3),
                              "peak_Tmad_per_s": 28.6,
-                             "note": "v_mad_u64_u32 count = points x 16 window digits x ~1550 mads per mixed addition (8 products + 2 squarings of 9x29-bit limbs); "
+                             "note": "v_mad_u64_u32 count = points x 16 window digits x ~1470 mads per mixed addition (8 products + 2 squarings of 9x29-bit limbs, two of them sharing a reduction); "
                                      "peak = 256 CU x 4 SIMD x 64 lanes x 2.4 GHz / 5.5 cycles (tools/microbench.hip)"},
-                         "note": "integer-VALU bound: ~2.4k VALU instructions (1.55k v_mad_u64_u32) per mixed addition at ~5.1 cycles each, 16 additions per 96-byte point; see DESIGN.md 3.3"},
+                         "note": "integer-VALU bound: ~2.25k VALU instructions (1.47k v_mad_u64_u32) per mixed addition at ~5.1 cycles each, 16 additions per 96-byte point; see DESIGN.md 3.3"},
         }
         if batch is not None:
             out["batch_throughput"] = batch

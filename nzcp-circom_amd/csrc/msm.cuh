@@ -24,7 +24,7 @@
 //      wavefront with __shfl_down of the limbs; msm_to_canon_kernel: back to the canonical image.
 //   Window sums (W + 1 points) go back to the host, which does the c*W doublings (internal.h).
 //
-// Roofline note: ~2.4k VALU instructions (1.55k v_mad_u64_u32) per
+// Roofline note: ~2.25k VALU instructions (1.47k v_mad_u64_u32) per
 // gathered point addition, 16 additions per 96 algorithmic bytes: integer-issue bound, not HBM bound.
 #pragma once
 #include <stdlib.h>
