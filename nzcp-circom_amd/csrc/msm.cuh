@@ -84,7 +84,7 @@ inline uint32_t msm_seg_len(bool dense = false) {
     if (v < 1) v = 1;
     if (v > 64) v = 64;
     const char* ed = getenv("G16_SEG_LEN_DENSE");
-    vd = ed ? (uint32_t)atoi(ed) : v;
+    vd = ed ? (uint32_t)atoi(ed) : (e ? v : 8u);   // measured on the H-MSM: reduce + tree 0.62 ms at 16, 0.55 at 8, 0.80 at 4
     if (vd < 1) vd = 1;
     if (vd > 64) vd = 64;
   }
