@@ -129,6 +129,26 @@ int g16_fr_batch_mul(int device, const uint8_t* a, const uint8_t* b, uint8_t* ou
  * a[i]+b[i] on the device (curve 1 = G1, 2 = G2; LEM affine in, STANDARD affine out). */
 int g16_field_op(int device, int field, int op, const uint8_t* a, const uint8_t* b, uint8_t* out, size_t n);
 int g16_ec_add(int device, int curve, const uint8_t* a, const uint8_t* b, uint8_t* out, size_t n);
+/* Layer tests of the arithmetic the kernels actually run (fq29.cuh / fr29.cuh / ec29.cuh: 9 x 29-bit limbs,
+ * lazy reduction, Montgomery radix 2^261), the device twins of wasmcurves' f1m_mul / f1m_square / curve add [EXT].
+ * Elements are RAW limb images: 9 little-endian u32 limbs + 1 pad word = 40 bytes, value = sum l[i] 2^(29 i)
+ * (limbs 0..7 below 2^29; the value may exceed p: the format is lazy), so tests can place inputs at the bounds
+ * the kernels rely on.  field 0 = Fr, 1 = Fq.  op: 0 mul(a,b)  1 sqr(a)  2 a*b + c*d (one reduction)
+ * 3 a^2 + c*d  4 a+b  5 a+2p-b  6 a+6p-b  7 a+4p-b-2c  8 2p-a  9 mul (row-wise variant)  10 weak_reduce (Fr)
+ * 11 zero tests: limb 0 = (a == 0 mod p), limb 1 = the low-limb filter f29_maybe_zero<7>.  b/c/d may be NULL
+ * when the op ignores them. */
+int g16_f29_op(int device, int field, int op, const uint8_t* a, const uint8_t* b, const uint8_t* c,
+               const uint8_t* d, uint8_t* out, size_t n);
+/* XYZZ point formulas over that field.  curve 1 = G1 (coordinate = 40 B), 2 = G2 (80 B: a | b of a + b u).
+ * acc / out: n XYZZ images (x | y | zz | zzz); q: n affine images (x | y) for op 0, 1, 4, n XYZZ images for op 2.
+ * op 0 = x29_madd_fast, the exception-free hot-loop formula (flags[i] = 1 when it asks for the redo pass),
+ * 1 = x29_madd (complete), 2 = x29_add, 3 = x29_dbl, 4 = x29_madd after a pack/unpack round trip of q (the
+ * resident 64/128-byte base format). */
+int g16_x29_op(int device, int curve, int op, const uint8_t* acc, const uint8_t* q, uint8_t* out, uint8_t* flags,
+               size_t n);
+/* [EXT] snarkjs groth16_prove.js buildABC1 on a staged witness: A_T, B_T, C_T = A_T o B_T as canonical
+ * Montgomery(2^256) residues, domain_size * 32 bytes each. */
+int g16_qap_eval(g16_prover* p, uint32_t slot, uint8_t* a, uint8_t* b, uint8_t* c);
 int g16_g1_multiexp(int device, const uint8_t* bases, const uint8_t* scalars, size_t n,
                     int window_bits, uint8_t out[64]);
 int g16_g2_multiexp(int device, const uint8_t* bases, const uint8_t* scalars, size_t n,

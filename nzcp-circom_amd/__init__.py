@@ -54,7 +54,8 @@ EXPORTS = ["g16_create", "g16_prove", "g16_prove_batch", "g16_stage_witness", "g
            "g16_last_error", "g16_fr_fft", "g16_fr_ifft", "g16_fr_batch_mul", "g16_field_op",
            "g16_ec_add", "g16_g1_multiexp", "g16_g2_multiexp", "g16_synth_setup",
            "g16_synth_witness", "g16_free", "g16_finish_host", "g16_shard_range", "g16_r1cs_setup",
-           "g16_sha256_chain_setup", "g16_sha256_message_setup", "g16_nzcp_fixed_layout_setup"]
+           "g16_sha256_chain_setup", "g16_sha256_message_setup", "g16_nzcp_fixed_layout_setup",
+           "g16_f29_op", "g16_x29_op", "g16_qap_eval"]
 
 
 def load():
@@ -85,6 +86,9 @@ def load():
     lib.g16_fr_batch_mul.argtypes = [C.c_int, C.c_char_p, C.c_char_p, C.c_char_p, sz, C.c_int]
     lib.g16_field_op.argtypes = [C.c_int, C.c_int, C.c_int, C.c_char_p, C.c_char_p, C.c_char_p, sz]
     lib.g16_ec_add.argtypes = [C.c_int, C.c_int, C.c_char_p, C.c_char_p, C.c_char_p, sz]
+    lib.g16_f29_op.argtypes = [C.c_int, C.c_int, C.c_int, C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, sz]
+    lib.g16_x29_op.argtypes = [C.c_int, C.c_int, C.c_int, C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, sz]
+    lib.g16_qap_eval.argtypes = [vp, C.c_uint32, C.c_char_p, C.c_char_p, C.c_char_p]
     lib.g16_g1_multiexp.argtypes = [C.c_int, C.c_char_p, C.c_char_p, sz, C.c_int, C.c_char_p]
     lib.g16_g2_multiexp.argtypes = [C.c_int, C.c_char_p, C.c_char_p, sz, C.c_int, C.c_char_p]
     lib.g16_synth_setup.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint64, C.c_int,
@@ -202,6 +206,13 @@ class Prover:
         _check(load().g16_prove_finish(self._h, slot, blob, len(partials), r, s, C.byref(pr), pub))
         return self._unpack(pr, pub)
 
+    def qap_eval(self, slot):
+        """buildABC1 of a staged witness -> (A_T, B_T, C_T) as lists of canonical Montgomery(2^256) residues."""
+        n = self.info.domain_size
+        bufs = [C.create_string_buffer(n * 32) for _ in range(3)]
+        _check(load().g16_qap_eval(self._h, slot, *bufs))
+        return [[int.from_bytes(b.raw[i * 32:(i + 1) * 32], "little") for i in range(n)] for b in bufs]
+
     def timings(self):
         t = Timings()
         _check(load().g16_get_timings(self._h, C.byref(t)))
@@ -243,6 +254,57 @@ def ec_add(curve, a, b, device=0):
     out = C.create_string_buffer(len(a))
     _check(load().g16_ec_add(device, curve, a, b, out, len(a) // psz))
     return out.raw
+
+
+# raw limb images of the kernels' lazy 9 x 29-bit format (layer tests of the arithmetic the hot path runs)
+F29_BYTES = 40
+
+
+def f29_pack(v):
+    """int (below 2^293) -> raw F29 image: limbs 0..7 of 29 bits, limb 8 takes the rest, one pad word."""
+    out = bytearray(F29_BYTES)
+    for i in range(8):
+        out[4 * i:4 * i + 4] = ((v >> (29 * i)) & 0x1FFFFFFF).to_bytes(4, "little")
+    out[32:36] = (v >> 232).to_bytes(4, "little")
+    return bytes(out)
+
+
+def f29_unpack(b):
+    return sum(int.from_bytes(b[4 * i:4 * i + 4], "little") << (29 * i) for i in range(9))
+
+
+def f29_op(field, op, a, b=None, c=None, d=None, device=0):
+    """a..d: lists of ints (values of the lazy elements) -> list of ints."""
+    n = len(a)
+    enc = [None if v is None else b"".join(f29_pack(x) for x in v) for v in (a, b, c, d)]
+    out = C.create_string_buffer(n * F29_BYTES)
+    _check(load().g16_f29_op(device, field, op, enc[0], enc[1], enc[2], enc[3], out, n))
+    return [f29_unpack(out.raw[i * F29_BYTES:(i + 1) * F29_BYTES]) for i in range(n)]
+
+
+def x29_op(curve, op, acc, q=None, device=0):
+    """acc: list of XYZZ coordinate tuples (4 ints for G1, 4 pairs for G2); q: affine (2) or XYZZ (4) tuples.
+    -> (list of XYZZ tuples, list of redo flags)."""
+    n = len(acc)
+
+    def enc(pts):
+        if pts is None:
+            return None
+        if curve == 1:
+            return b"".join(f29_pack(x) for pt in pts for x in pt)
+        return b"".join(f29_pack(x) for pt in pts for co in pt for x in co)
+    cb = F29_BYTES * (2 if curve == 2 else 1)
+    out = C.create_string_buffer(n * 4 * cb)
+    flags = C.create_string_buffer(max(1, n))
+    _check(load().g16_x29_op(device, curve, op, enc(acc), enc(q), out, flags, n))
+    res = []
+    for i in range(n):
+        co = []
+        for k in range(4):
+            raw = out.raw[(4 * i + k) * cb:(4 * i + k + 1) * cb]
+            co.append(f29_unpack(raw) if curve == 1 else (f29_unpack(raw[:F29_BYTES]), f29_unpack(raw[F29_BYTES:])))
+        res.append(tuple(co))
+    return res, list(flags.raw[:n])
 
 
 def multiexp(curve, bases, scalars, window_bits=0, device=0):

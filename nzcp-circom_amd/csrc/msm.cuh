@@ -29,6 +29,8 @@
 #pragma once
 #include <stdlib.h>
 
+#include <atomic>
+
 #include "ec29.cuh"
 #include "internal.h"
 
@@ -77,18 +79,20 @@ static constexpr uint32_t kSegLenDefault = 16;   // buckets per reduce segment (
 // `dense` (the H-MSM): its reduce is the exposed tail of the proof, so shorter segments (more lanes, shorter
 // chains) pay; the witness MSMs reduce while the H-MSM accumulates, where extra VALU work only competes.
 inline uint32_t msm_seg_len(bool dense = false) {
-  static uint32_t v = 0, vd = 0;
-  if (!v) {
+  struct Cfg { uint32_t v, vd; };
+  static const Cfg cfg = [] {   // thread-safe one-time initialisation (two host threads may prove on two handles)
+    Cfg c;
     const char* e = getenv("G16_SEG_LEN");
-    v = e ? (uint32_t)atoi(e) : kSegLenDefault;
-    if (v < 1) v = 1;
-    if (v > 64) v = 64;
+    c.v = e ? (uint32_t)atoi(e) : kSegLenDefault;
+    if (c.v < 1) c.v = 1;
+    if (c.v > 64) c.v = 64;
     const char* ed = getenv("G16_SEG_LEN_DENSE");
-    vd = ed ? (uint32_t)atoi(ed) : (e ? v : 8u);   // measured on the H-MSM: reduce + tree 0.62 ms at 16, 0.55 at 8, 0.80 at 4
-    if (vd < 1) vd = 1;
-    if (vd > 64) vd = 64;
-  }
-  return dense ? vd : v;
+    c.vd = ed ? (uint32_t)atoi(ed) : (e ? c.v : 8u);   // measured on the H-MSM: reduce + tree 0.62 ms at 16, 0.55 at 8, 0.80 at 4
+    if (c.vd < 1) c.vd = 1;
+    if (c.vd > 64) c.vd = 64;
+    return c;
+  }();
+  return dense ? cfg.vd : cfg.v;
 }
 
 __device__ __forceinline__ uint32_t msm_extract(const uint32_t s[8], int pos, int c) {
@@ -722,11 +726,17 @@ int msm_launch_t(const MsmInstance& m, MsmWorkspace* ws, const Fr* d_scalars, hi
   const uint32_t chunks = ws->chunks, per = (ne + chunks - 1) / chunks;
   const size_t lds_bytes = (size_t)B * 4;
   {
-    static bool attr_done = false;   // > 64 KiB of dynamic LDS needs the opt-in (c = 16: 128 KiB histogram)
-    if (!attr_done) {
+    // > 64 KiB of dynamic LDS needs the opt-in (c = 16: 128 KiB histogram).  The attribute is set once PER DEVICE
+    // (one process may hold handles on several GPUs: the Node host of BASELINE config 4) and per template
+    // instantiation (the kernels are static to each translation unit).
+    static std::atomic<uint64_t> attr_mask{0};
+    int dev = 0;
+    G16_HIP(hipGetDevice(&dev));
+    const uint64_t bit = 1ull << (dev & 63);
+    if (!(attr_mask.load(std::memory_order_acquire) & bit)) {
       G16_HIP(hipFuncSetAttribute((const void*)msm_sort_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
       G16_HIP(hipFuncSetAttribute((const void*)msm_sort_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-      attr_done = true;
+      attr_mask.fetch_or(bit, std::memory_order_release);
     }
   }
   static const bool trace = getenv("G16_TRACE_HOST") != nullptr;

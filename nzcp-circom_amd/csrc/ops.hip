@@ -6,6 +6,8 @@
 
 #include <memory>
 
+#include "ec29.cuh"
+#include "fr29.cuh"
 #include "internal.h"
 
 namespace g16 {
@@ -160,6 +162,62 @@ static int fft_impl(int device, uint8_t* buf, size_t n, bool inverse) {
   return rc;
 }
 
+
+// ---------------------------------------------------------------------------------------------------
+// Layer tests of the arithmetic the hot path actually runs: the 9 x 29-bit lazy field (fq29.cuh / fr29.cuh)
+// and the XYZZ formulas over it (ec29.cuh).  Elements travel as RAW limb images (F29: nine u32 limbs + one
+// pad word, value = sum l[i] 2^(29 i)), so a test can place inputs at the documented bounds (X < 5.4p, ...).
+template <class C>
+__global__ void f29_op_kernel(const F29* a, const F29* b, const F29* c, const F29* d, F29* out, size_t n, int op) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const F29 x = a[i], y = b[i], z = c[i], w = d[i];
+  F29 r;
+  switch (op) {
+    case 0: r = f29_mul<C>(x, y); break;
+    case 1: r = f29_sqr<C>(x); break;
+    case 2: r = f29_mul2<C>(x, y, z, w); break;       // x*y + z*w, one reduction (== Fq29Ops::mul_add)
+    case 3: r = f29_sqr_mul<C>(x, z, w); break;       // x^2 + z*w, one reduction
+    case 4: r = f29_add<C>(x, y); break;
+    case 5: r = f29_sub<2, C>(x, y); break;
+    case 6: r = f29_sub<6, C>(x, y); break;
+    case 7: r = f29_sub_b_2c<C>(x, y, z); break;      // x + 4p - y - 2z
+    case 8: r = f29_neg<2, C>(x); break;
+    case 9: r = f29_mul_rows<C>(x, y); break;
+    case 10: r = fr29_weak_reduce(x); break;          // Fr only
+    case 11: { r = f29_zero(); r.l[0] = f29_is_zero<C>(x) ? 1u : 0u; r.l[1] = f29_maybe_zero<7, C>(x) ? 1u : 0u; break; }
+    default: r = f29_zero(); break;
+  }
+  r.pad_ = 0;
+  out[i] = r;
+}
+
+// op 0: x29_madd_fast (flag = its redo request), 1: x29_madd, 2: x29_add (q is an XYZZ image), 3: x29_dbl,
+// 4: pack -> unpack round trip of the affine q (the resident base format of the accumulate kernel), then madd
+template <class F>
+__global__ void x29_op_kernel(const XYZZ<F>* acc_in, const void* q_in, XYZZ<F>* out, uint8_t* flags, size_t n, int op) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  XYZZ<F> acc = acc_in[i];
+  bool fl = false;
+  if (op == 2) {
+    const XYZZ<F> q = reinterpret_cast<const XYZZ<F>*>(q_in)[i];
+    x29_add(acc, q);
+  } else if (op == 3) {
+    x29_dbl(acc);
+  } else {
+    Affine<F> q = reinterpret_cast<const Affine<F>*>(q_in)[i];
+    if (op == 4) {
+      PackedAffine<F> pk;
+      a29_pack(pk, q);
+      a29_unpack(q, pk);
+    }
+    if (op == 0) fl = x29_madd_fast(acc, q);
+    else x29_madd(acc, q);
+  }
+  out[i] = acc;
+  if (flags) flags[i] = fl ? 1 : 0;
+}
 }  // namespace g16
 
 using namespace g16;
@@ -199,6 +257,50 @@ int g16_g1_multiexp(int device, const uint8_t* bases, const uint8_t* scalars, si
 int g16_g2_multiexp(int device, const uint8_t* bases, const uint8_t* scalars, size_t n, int window_bits,
                     uint8_t out[128]) {
   return multiexp_impl<Fq2Ops>(device, 2, bases, scalars, n, window_bits, out);
+}
+
+int g16_f29_op(int device, int field, int op, const uint8_t* a, const uint8_t* b, const uint8_t* c, const uint8_t* d,
+               uint8_t* out, size_t n) {
+  int rc = dev_check(device);
+  if (rc) return rc;
+  if (!a || !out || op < 0 || op > 11 || (op == 10 && field != 0)) { set_error("g16_f29_op: bad argument"); return G16_E_ARG; }
+  DevBuf dv[4], dout;
+  const uint8_t* src[4] = {a, b ? b : a, c ? c : a, d ? d : a};
+  const size_t bytes = n * sizeof(F29);
+  for (int k = 0; k < 4; k++) {
+    if ((rc = dv[k].alloc(bytes))) return rc;
+    G16_HIP(hipMemcpy(dv[k].p, src[k], bytes, hipMemcpyHostToDevice));
+  }
+  if ((rc = dout.alloc(bytes))) return rc;
+  const unsigned nb = (unsigned)((n + 255) / 256);
+  if (field == 0)
+    f29_op_kernel<Fr29C><<<nb, 256>>>((const F29*)dv[0].p, (const F29*)dv[1].p, (const F29*)dv[2].p, (const F29*)dv[3].p, (F29*)dout.p, n, op);
+  else
+    f29_op_kernel<Fq29C><<<nb, 256>>>((const F29*)dv[0].p, (const F29*)dv[1].p, (const F29*)dv[2].p, (const F29*)dv[3].p, (F29*)dout.p, n, op);
+  G16_HIP(hipGetLastError());
+  G16_HIP(hipMemcpy(out, dout.p, bytes, hipMemcpyDeviceToHost));
+  return G16_OK;
+}
+
+int g16_x29_op(int device, int curve, int op, const uint8_t* acc, const uint8_t* q, uint8_t* out, uint8_t* flags, size_t n) {
+  int rc = dev_check(device);
+  if (rc) return rc;
+  if (!acc || !out || op < 0 || op > 4 || (op != 3 && !q)) { set_error("g16_x29_op: bad argument"); return G16_E_ARG; }
+  const size_t coord = curve == 2 ? sizeof(F29x2) : sizeof(F29);
+  const size_t ab = n * 4 * coord, qb = n * (op == 2 ? 4 : 2) * coord;
+  DevBuf da, dq, dout, dfl;
+  if ((rc = da.alloc(ab)) || (rc = dq.alloc(qb)) || (rc = dout.alloc(ab)) || (rc = dfl.alloc(n))) return rc;
+  G16_HIP(hipMemcpy(da.p, acc, ab, hipMemcpyHostToDevice));
+  if (q) G16_HIP(hipMemcpy(dq.p, q, qb, hipMemcpyHostToDevice));
+  const unsigned nb = (unsigned)((n + 63) / 64);
+  if (curve == 2)
+    x29_op_kernel<Fq2x29Ops><<<nb, 64>>>((const G2XYZZ29*)da.p, dq.p, (G2XYZZ29*)dout.p, (uint8_t*)dfl.p, n, op);
+  else
+    x29_op_kernel<Fq29Ops><<<nb, 64>>>((const G1XYZZ29*)da.p, dq.p, (G1XYZZ29*)dout.p, (uint8_t*)dfl.p, n, op);
+  G16_HIP(hipGetLastError());
+  G16_HIP(hipMemcpy(out, dout.p, ab, hipMemcpyDeviceToHost));
+  if (flags) G16_HIP(hipMemcpy(flags, dfl.p, n, hipMemcpyDeviceToHost));
+  return G16_OK;
 }
 
 }  // extern "C"

@@ -269,7 +269,7 @@ static int create_impl(const uint8_t* zkey, size_t len, const g16_opts* opts, g1
   P->nPublic = rd32(h + 4);
   P->N = rd32(h + 8);
   h += 12;
-  if (P->N == 0 || (P->N & (P->N - 1)) || P->nPublic + 1 > P->nVars) {
+  if (P->N == 0 || (P->N & (P->N - 1)) || (uint64_t)P->nPublic + 1 > (uint64_t)P->nVars) {
     set_error("zkey: Invalid File format");
     return G16_E_FORMAT;
   }
@@ -682,6 +682,10 @@ int g16_prove_finish(g16_prover* p, uint32_t slot, const uint8_t* partials, uint
   if (!p || !partials || !count || !out) { set_error("NULL argument"); return G16_E_ARG; }
   std::lock_guard<std::mutex> lk(p->mu);
   if (slot >= p->slot_pub.size()) { set_error("witness slot not staged"); return G16_E_STATE; }
+  if (count != (uint32_t)p->shard_count) {   // a missing (or extra) partial would silently give an invalid proof
+    set_error("g16_prove_finish: expected " + std::to_string(p->shard_count) + " partial sums, got " + std::to_string(count));
+    return G16_E_ARG;
+  }
   std::vector<Partial> parts(count);
   memcpy(parts.data(), partials, (size_t)count * sizeof(Partial));
   int rc = finish_impl(&p->kp, parts.data(), count, r, s, out);
@@ -799,6 +803,26 @@ int g16_get_info(const g16_prover* p, g16_info* o) {
 int g16_get_timings(const g16_prover* p, g16_timings* o) {
   if (!p || !o) { set_error("NULL argument"); return G16_E_ARG; }
   *o = p->tm;
+  return G16_OK;
+}
+
+// Operator-level twin of snarkjs `buildABC1` (layer test): A_T, B_T, C_T of the staged witness as
+// canonical Montgomery(2^256) residues, domainSize * 32 bytes each (what wasmcurves holds after buildABC1).
+int g16_qap_eval(g16_prover* p, uint32_t slot, uint8_t* a, uint8_t* b, uint8_t* c) {
+  if (!p || !a || !b || !c) { set_error("NULL argument"); return G16_E_ARG; }
+  std::lock_guard<std::mutex> lk(p->mu);
+  if (slot >= p->slot_dev.size() || !p->slot_dev[slot]) { set_error("witness slot not staged"); return G16_E_STATE; }
+  G16_HIP(hipSetDevice(p->device));
+  ProofCtx& cx = p->ctx[0];
+  int rc = qap_eval(p->csr, p->slot_dev[slot], cx.d_a, cx.d_b, cx.d_c, cx.st);
+  if (rc) return rc;
+  const F29* src[3] = {cx.d_a, cx.d_b, cx.d_c};
+  uint8_t* dst[3] = {a, b, c};
+  for (int k = 0; k < 3; k++) {
+    if ((rc = ntt_export(p->ntt, src[k], cx.d_p, false, false, cx.st))) return rc;
+    G16_HIP(hipMemcpyAsync(dst[k], cx.d_p, (size_t)p->N * sizeof(Fr), hipMemcpyDeviceToHost, cx.st));
+    G16_HIP(hipStreamSynchronize(cx.st));
+  }
   return G16_OK;
 }
 

@@ -27,13 +27,24 @@
     }                                                                         \
   } while (0)
 
+/* `inflight` and `closing` are touched on the main (JS) thread only: jobs are queued by js_prove* and retired by
+ * job_complete, both of which run there.  destroy() while a proof is queued or running only marks the handle;
+ * the native prover (its mutex, streams, HBM buffers) is released when the last job retires -- never under a
+ * worker thread that still dereferences it. */
 typedef struct {
   g16_prover* p;
+  uint32_t inflight;
+  int closing;
 } handle_t;
 
-static void handle_finalize(napi_env env, void* data, void* hint) {
-  handle_t* h = (handle_t*)data;
+static void handle_release(handle_t* h) {
   if (h->p) g16_destroy(h->p);
+  h->p = NULL;
+}
+
+static void handle_finalize(napi_env env, void* data, void* hint) {
+  handle_t* h = (handle_t*)data;   /* no job can be in flight: every job holds a reference on the external */
+  handle_release(h);
   free(h);
 }
 
@@ -106,6 +117,10 @@ static void job_complete(napi_env env, napi_status status, void* data) {
     napi_set_named_property(env, result, "pub", pub);
     napi_resolve_deferred(env, j->deferred, result);
   }
+  if (j->h) {   /* prove / proveBatch: retire the job; a destroy() issued meanwhile takes effect now */
+    j->h->inflight--;
+    if (j->h->closing && j->h->inflight == 0) handle_release(j->h);
+  }
   for (int i = 0; i < j->nrefs; i++) napi_delete_reference(env, j->refs[i]);
   if (j->brefs) { for (size_t i = 0; i < j->bcount; i++) napi_delete_reference(env, j->brefs[i]); free(j->brefs); }
   napi_delete_async_work(env, j->work);
@@ -168,9 +183,9 @@ static napi_value js_prove(napi_env env, napi_callback_info info) {
   NAPI_OK(napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
   handle_t* h = NULL;
   bool isbuf = false;
-  if (argc < 2 || napi_get_value_external(env, argv[0], (void**)&h) != napi_ok || !h || !h->p ||
+  if (argc < 2 || napi_get_value_external(env, argv[0], (void**)&h) != napi_ok || !h || !h->p || h->closing ||
       napi_is_buffer(env, argv[1], &isbuf) != napi_ok || !isbuf) {
-    napi_throw_type_error(env, NULL, "prove(handle, wtns: Buffer, r, s)");
+    napi_throw_type_error(env, NULL, "prove(handle, wtns: Buffer, r, s): bad arguments or handle already destroyed");
     return NULL;
   }
   job_t* j = (job_t*)calloc(1, sizeof(job_t));
@@ -193,6 +208,7 @@ static napi_value js_prove(napi_env env, napi_callback_info info) {
   g16_get_info(h->p, &inf);
   j->pub_len = (size_t)inf.n_public * 32;
   j->pub = (uint8_t*)malloc(j->pub_len ? j->pub_len : 1);
+  h->inflight++;
   return queue_job(env, j, "g16_prove");
 }
 
@@ -205,14 +221,13 @@ static napi_value js_prove_batch(napi_env env, napi_callback_info info) {
   handle_t* h = NULL;
   bool isarr = false, isbuf = false;
   uint32_t n = 0;
-  if (argc < 2 || napi_get_value_external(env, argv[0], (void**)&h) != napi_ok || !h || !h->p ||
+  if (argc < 2 || napi_get_value_external(env, argv[0], (void**)&h) != napi_ok || !h || !h->p || h->closing ||
       napi_is_array(env, argv[1], &isarr) != napi_ok || !isarr || napi_get_array_length(env, argv[1], &n) != napi_ok || n == 0) {
     napi_throw_type_error(env, NULL, "proveBatch(handle, wtns: Buffer[], rs)");
     return NULL;
   }
   job_t* j = (job_t*)calloc(1, sizeof(job_t));
   j->is_create = 2;
-  j->h = h;
   j->bcount = n;
   j->bw = (const uint8_t**)calloc(n, sizeof(uint8_t*));
   j->blen = (size_t*)calloc(n, sizeof(size_t));
@@ -241,6 +256,8 @@ static napi_value js_prove_batch(napi_env env, napi_callback_info info) {
     j->brs = (uint8_t*)malloc(len);
     memcpy(j->brs, data, len);
   }
+  j->h = h;   /* set last: the early error returns above must not retire a job that was never counted */
+  h->inflight++;
   return queue_job(env, j, "g16_prove_batch");
 }
 
@@ -292,8 +309,8 @@ static napi_value js_destroy(napi_env env, napi_callback_info info) {
   handle_t* h = NULL;
   NAPI_OK(napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
   if (argc >= 1 && napi_get_value_external(env, argv[0], (void**)&h) == napi_ok && h && h->p) {
-    g16_destroy(h->p);
-    h->p = NULL;
+    h->closing = 1;                       /* no new jobs; info()/timings() stay valid until the release */
+    if (h->inflight == 0) handle_release(h);
   }
   return NULL;
 }

@@ -71,16 +71,20 @@ class Prover {
   get timings() { return native().timings(this._h); }
   // one in-flight prove per handle: serialise callers
   prove(wtns, opts = {}) {
-    const w = toBuffer(wtns, "wtns");
-    const run = () => native().prove(this._h, w, scalarToBuffer(opts.r), scalarToBuffer(opts.s))
+    if (!this._h) return Promise.reject(new Error("prover is closed"));
+    const w = toBuffer(wtns, "wtns"), h = this._h;
+    const run = () => native().prove(h, w, scalarToBuffer(opts.r), scalarToBuffer(opts.s))
       .then(({ proof, pub }) => ({ proof: proofObject(proof), publicSignals: publicSignals(pub) }));
     const p = this._busy.then(run, run);
     this._busy = p.catch(() => {});
     return p;
   }
   // Batch of independent witnesses against the resident key (g16_prove_batch: the library overlaps
-  // proof i+1's device work with proof i's tail).  opts.r / opts.s apply to every proof when given.
+  // proof i+1's device work with proof i's tail).  opts.r / opts.s are TEST-ONLY: they pin ONE blinding pair
+  // for every proof of the batch (reproducible bytes), which breaks zero-knowledge across the batch -- leave
+  // them unset in production and every proof draws its own (r, s) from the OS CSPRNG.
   proveBatch(wtnsList, opts = {}) {
+    if (!this._h) return Promise.reject(new Error("prover is closed"));
     const ws = wtnsList.map((w) => toBuffer(w, "wtns"));
     let rs = null;
     const r = scalarToBuffer(opts.r), s = scalarToBuffer(opts.s);
@@ -88,13 +92,22 @@ class Prover {
       rs = Buffer.alloc(ws.length * 64);
       for (let i = 0; i < ws.length; i++) { r.copy(rs, i * 64); s.copy(rs, i * 64 + 32); }
     }
-    const run = () => native().proveBatch(this._h, ws, rs)
+    const h = this._h;
+    const run = () => native().proveBatch(h, ws, rs)
       .then((list) => list.map(({ proof, pub }) => ({ proof: proofObject(proof), publicSignals: publicSignals(pub) })));
     const p = this._busy.then(run, run);
     this._busy = p.catch(() => {});
     return p;
   }
-  close() { if (this._h) { native().destroy(this._h); this._h = null; } }
+  // Releases the resident key.  Proofs already requested (awaited or not) finish first: the native handle is
+  // destroyed after the last of them settles, never under a running proof.  Returns a Promise.
+  close() {
+    if (!this._h) return this._busy;
+    const h = this._h;
+    this._h = null;
+    this._busy = this._busy.then(() => native().destroy(h));
+    return this._busy;
+  }
 }
 
 async function createProver(zkey, opts = {}) {
@@ -114,7 +127,7 @@ const groth16 = {
     try {
       return await prover.prove(wtns, opts);
     } finally {
-      prover.close();
+      await prover.close();
     }
   },
   createProver,

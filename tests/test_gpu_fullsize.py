@@ -124,6 +124,49 @@ def test_config3_batch_throughput_mode(amd):
     prover.close()
 
 
+def test_config3_batch_nominal(amd):
+    """config 3 AS STATED in BASELINE.json: a batch of 1 024 independent nzcp_live proofs (n = 1.7 M, the upper
+    structural estimate) through ONE g16_prove_batch call, cycling 8 distinct witnesses with a fresh blinding pair
+    for every proof.  Every proof must equal its one-by-one result (same witness, same (r, s)); the first, the
+    last and a random one are pairing-verified against the setup's verification key."""
+    n, seed, count, distinct = 1_700_000, synth.SEED_NZCP, 1024, 8
+    zkey, wtns0, vkey = amd.synth_setup(n, P_NZCP, n, seed)
+    vk = _vk(vkey)
+    wts = [wtns0] + [amd.synth_witness(n, P_NZCP, n, seed, seed + 200 + i) for i in range(1, distinct)]
+    assert len({hashlib.sha256(w).digest() for w in wts}) == distinct
+    lib = amd.load()
+    prover = amd.Prover(zkey)
+    del zkey
+    # the blinding pairs cycle with period 9 (coprime to 8): 72 distinct (witness, r, s) triples, each checked once
+    # against a one-by-one proof, every batch proof compared with the triple it repeats
+    rs = [_rs(seed + 1000 + i) for i in range(9)]
+    arr = (ctypes.c_char_p * count)(*[wts[i % distinct] for i in range(count)])
+    lens = (ctypes.c_size_t * count)(*[len(wts[i % distinct]) for i in range(count)])
+    rsbuf = b"".join(f.le(rs[i % 9][0]) + f.le(rs[i % 9][1]) for i in range(count))
+    proofs = (amd.Proof * count)()
+    pubs = ctypes.create_string_buffer(count * P_NZCP * 32)
+    rc = lib.g16_prove_batch(prover._h, arr, lens, count, rsbuf, proofs, pubs)
+    assert rc == 0, lib.g16_last_error()
+    ref = {}
+    pr, gpub = amd.Proof(), ctypes.create_string_buffer(P_NZCP * 32)
+    for k in range(72):
+        wi, ri = k % distinct, k % 9
+        prover.stage(0, wts[wi])
+        assert prover.prove_staged_raw(0, f.le(rs[ri][0]), f.le(rs[ri][1]), pr, gpub) == 0
+        ref[(wi, ri)] = (bytes(pr.a) + bytes(pr.b) + bytes(pr.c), gpub.raw)
+    assert len({v[0] for v in ref.values()}) == 72
+    for i in range(count):
+        want, wpub = ref[(i % distinct, i % 9)]
+        assert bytes(proofs[i].a) + bytes(proofs[i].b) + bytes(proofs[i].c) == want, i
+        assert pubs.raw[i * P_NZCP * 32:(i + 1) * P_NZCP * 32] == wpub, i
+    for i in (0, count - 1, 517):
+        raw = pubs.raw[i * P_NZCP * 32:(i + 1) * P_NZCP * 32]
+        pub = [str(f.from_le(raw[k * 32:(k + 1) * 32])) for k in range(P_NZCP)]
+        assert pub == _pub_of(wts[i % distinct])
+        assert _verifies(vk, pub, amd.proof_to_obj(proofs[i]))
+    prover.close()
+
+
 def _bits_msb_first(data):
     return [str((byte >> (7 - k)) & 1) for byte in data for k in range(8)]
 

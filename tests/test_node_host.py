@@ -87,6 +87,48 @@ def test_resident_prover_and_random_blinding(addon):
 
 
 @needs_node
+@pytest.mark.gpu
+def test_close_while_proofs_are_in_flight(addon):
+    """ADVICE r1 (use-after-free): `p.prove(w).then(..); p.close()` must not delete the native handle under the
+    running proof.  JS level: close() waits for requested proofs.  Addon level: destroy() on a handle with a job
+    queued or running is deferred until that job retires, and new jobs are refused meanwhile."""
+    meta = json.load(open(golden_path("small.json")))
+    script = f"""
+    const {{ groth16 }} = require({json.dumps(JS)});
+    const native = require({json.dumps(addon)});
+    const fs = require("fs");
+    (async () => {{
+      const w = {json.dumps(golden_path('small.wtns'))};
+      const pv = await groth16.createProver({json.dumps(golden_path('small.zkey'))});
+      const p1 = pv.prove(w, {{r: "{meta['r']}", s: "{meta['s']}"}});
+      const p2 = pv.prove(w, {{r: "{meta['r']}", s: "{meta['s']}"}});
+      const closed = pv.close();                       // not awaited proofs above
+      let after = "none";
+      try {{ await pv.prove(w); }} catch (e) {{ after = e.message; }}
+      const [a, b] = await Promise.all([p1, p2]);
+      await closed;
+      // raw addon: destroy right after queueing the job
+      const h = await native.create(fs.readFileSync({json.dumps(golden_path('small.zkey'))}), {{}});
+      const wb = fs.readFileSync(w);
+      const r = Buffer.alloc(32), s = Buffer.alloc(32);
+      const job = native.prove(h, wb, r, s);
+      native.destroy(h);
+      let refused = "none";
+      try {{ native.prove(h, wb, r, s); }} catch (e) {{ refused = e.message; }}
+      const res = await job;
+      console.log(JSON.stringify({{a, b, after, refused, rawlen: res.proof.length}}));
+    }})();
+    """
+    r = run_node(script)
+    assert r.returncode == 0, r.stderr
+    out = json.loads(r.stdout)
+    assert out["a"]["proof"] == meta["proof"] and out["b"]["proof"] == meta["proof"]
+    assert out["after"] == "prover is closed"
+    assert "already destroyed" in out["refused"]
+    assert out["rawlen"] == 256
+
+
+@needs_node
 def test_nzcp_input_builder_example_pass():
     """pass URI -> ToBeSigned / circuit input / expected public signals, pinned by the
     reference's golden data for the MoH example pass (URI = the test input at
