@@ -333,10 +333,10 @@ def main():
     if rank == 0:
         proof_obj = amd.proof_to_obj(pr)
         pub_list = [str(int.from_bytes(pub.raw[i * 32:(i + 1) * 32], "little")) for i in range(args.n_public)]
-        # roofline of the dominant kernel: the G1 bucket-accumulate launches (A, B1, C, H)
-        g1 = [0, 1, 3, 4]
-        pts = [info.n_a, info.n_b1, info.n_c, info.n_h]
-        launches = [(pts[j], acc["accum"][i] / K) for j, i in enumerate(g1) if pts[j] > 0]
+        # roofline of the dominant kernel: the G1 bucket-accumulate launches -- one over the fused witness group
+        # (the resident points of A, B1 and C) and one over H
+        launches = [(pts_, acc["accum"][i] / K) for pts_, i in ((info.n_a + info.n_b1 + info.n_c, 0), (info.n_h, 4))
+                    if pts_ > 0]
         bytes_per_launch = sum(96.0 * n for n, _ in launches) / max(1, len(launches))
         ms_per_launch = sum(ms for _, ms in launches) / max(1, len(launches))
         achieved = bytes_per_launch / (ms_per_launch * 1e-3) / 1e9 if ms_per_launch > 0 else 0.0
@@ -375,7 +375,7 @@ def main():
                           "witness_upload_pcie": round(upload_ms, 3)},
             "algorithmic_bytes_per_proof": b_proof,
             "proof_hbm_GBps": round(b_proof / (acc["total_ms"] / K * 1e-3) / 1e9, 2) if acc["total_ms"] else None,
-            "roofline": {"bound": "hbm", "kernel": "msm_accumulate_kernel<G1> (avg over the A,B1,C,H launches)",
+            "roofline": {"bound": "hbm", "kernel": "msm_accumulate_kernel<G1> (avg over its two launches per proof: fused witness group A+B1+C, and H)",
                          "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_note": traffic_note,
                          "algorithmic_bytes_per_launch": round(bytes_per_launch),

@@ -63,8 +63,10 @@ typedef struct g16_info {
 } g16_info;
 
 /* Per-phase device timings of the last g16_prove* on this handle, milliseconds (HIP events on the
- * prover's stream).  msm[] order: A, B1, B2, C, H.  *_kernel_ms are the bucket-accumulate kernels
- * alone (the roofline kernel of bench.py). */
+ * prover's streams).  The witness MSMs A, B1, C share one front end and one G1 bucket-accumulate launch, B2 rides
+ * on B1's buckets as the G2 lane: msm_ms[0] = that group's main chain, msm_ms[2] = until the G2 lane ends (traced
+ * runs only), msm_ms[4] = the H-MSM, [1] and [3] are 0.  *_kernel_ms are the bucket-accumulate kernels alone
+ * (the roofline kernel of bench.py): [0] = G1 over A+B1+C, [2] = G2 (B2), [4] = H. */
 typedef struct g16_timings {
   float upload_ms, qap_ms, ntt_ms, msm_ms[5], tail_ms, total_ms;
   float msm_accum_kernel_ms[5];
@@ -103,6 +105,22 @@ int g16_prove_staged(g16_prover* p, uint32_t slot, const uint8_t r[32], const ui
 int g16_prove_partial(g16_prover* p, uint32_t slot, uint8_t partial[G16_PARTIAL_BYTES]);
 int g16_prove_finish(g16_prover* p, uint32_t slot, const uint8_t* partials, uint32_t count,
                      const uint8_t r[32], const uint8_t s[32], g16_proof* out, uint8_t* pub);
+
+/* Multi-GPU with the H-polynomial pipeline sharded as well (SURVEY 8e "later: split A/B/C across GPUs"): instead
+ * of every shard repeating QAP + 6 NTTs, shard v mod count evaluates vector v (0 = A, 1 = B, 2 = C) on the odd
+ * coset and the shards exchange slices, so that each joins and multi-exponentiates only its own range of P:
+ *   g16_shard_begin  starts this shard's witness MSMs (they keep running) and, for every bit v of vec_mask,
+ *                    computes the coset evaluations of vector v and copies all domain_size elements to
+ *                    out_vecs[v] -- any memory the device can address (device, peer device, pinned or plain host);
+ *                    returns when the copies are complete.  Elements are G16_LAZY_FR_BYTES each (the kernels'
+ *                    9 x 29-bit lazy Montgomery image: opaque, only to be handed to g16_shard_end).
+ *   (exchange)       shard r needs elements [lo, hi) = g16_shard_range(domain_size, r, count) of all three vectors:
+ *                    an RCCL scatter / all-to-all between processes, peer copies inside one process.
+ *   g16_shard_end    takes the three slices ((hi - lo) elements each), joins P = A.B - C on the slice, runs the
+ *                    H-MSM over its bases and returns the partial sums exactly like g16_prove_partial. */
+#define G16_LAZY_FR_BYTES 40
+int g16_shard_begin(g16_prover* p, uint32_t slot, uint32_t vec_mask, void* const out_vecs[3]);
+int g16_shard_end(g16_prover* p, uint32_t slot, const void* const slices[3], uint8_t partial[G16_PARTIAL_BYTES]);
 
 /* Host-only assembly from gathered partials (no GPU handle needed; reads only the zkey header),
  * and the shard -> point-range map used by g16_create. */

@@ -17,6 +17,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libg16hip.so")
 PARTIAL_BYTES = 128 * 4 + 256
+LAZY_FR_BYTES = 40
 
 _lib = None
 
@@ -55,7 +56,7 @@ EXPORTS = ["g16_create", "g16_prove", "g16_prove_batch", "g16_stage_witness", "g
            "g16_ec_add", "g16_g1_multiexp", "g16_g2_multiexp", "g16_synth_setup",
            "g16_synth_witness", "g16_free", "g16_finish_host", "g16_shard_range", "g16_r1cs_setup",
            "g16_sha256_chain_setup", "g16_sha256_message_setup", "g16_nzcp_fixed_layout_setup",
-           "g16_f29_op", "g16_x29_op", "g16_qap_eval"]
+           "g16_f29_op", "g16_x29_op", "g16_qap_eval", "g16_shard_begin", "g16_shard_end"]
 
 
 def load():
@@ -89,6 +90,8 @@ def load():
     lib.g16_f29_op.argtypes = [C.c_int, C.c_int, C.c_int, C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, sz]
     lib.g16_x29_op.argtypes = [C.c_int, C.c_int, C.c_int, C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, sz]
     lib.g16_qap_eval.argtypes = [vp, C.c_uint32, C.c_char_p, C.c_char_p, C.c_char_p]
+    lib.g16_shard_begin.argtypes = [vp, C.c_uint32, C.c_uint32, C.POINTER(vp)]
+    lib.g16_shard_end.argtypes = [vp, C.c_uint32, C.POINTER(vp), C.c_char_p]
     lib.g16_g1_multiexp.argtypes = [C.c_int, C.c_char_p, C.c_char_p, sz, C.c_int, C.c_char_p]
     lib.g16_g2_multiexp.argtypes = [C.c_int, C.c_char_p, C.c_char_p, sz, C.c_int, C.c_char_p]
     lib.g16_synth_setup.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint64, C.c_int,
@@ -205,6 +208,19 @@ class Prover:
         blob = b"".join(partials)
         _check(load().g16_prove_finish(self._h, slot, blob, len(partials), r, s, C.byref(pr), pub))
         return self._unpack(pr, pub)
+
+    def shard_begin(self, slot, vec_mask, out_ptrs):
+        """Sharded H pipeline, first half: out_ptrs = three addresses (ints; 0 where the mask bit is clear) of
+        buffers of domain_size * LAZY_FR_BYTES bytes the device can write (host or device memory)."""
+        arr = (C.c_void_p * 3)(*[C.c_void_p(p or None) for p in out_ptrs])
+        _check(load().g16_shard_begin(self._h, slot, vec_mask, arr))
+
+    def shard_end(self, slot, slice_ptrs):
+        """... second half: the three slices [lo, hi) of this shard's H range -> the partial-sum blob."""
+        arr = (C.c_void_p * 3)(*[C.c_void_p(p or None) for p in slice_ptrs])
+        buf = C.create_string_buffer(PARTIAL_BYTES)
+        _check(load().g16_shard_end(self._h, slot, arr, buf))
+        return buf.raw
 
     def qap_eval(self, slot):
         """buildABC1 of a staged witness -> (A_T, B_T, C_T) as lists of canonical Montgomery(2^256) residues."""

@@ -78,65 +78,75 @@ int qap_convert_coefs(const Fr* in, F29* out, size_t n, hipStream_t st);
 struct MsmConfig {
   int c = 0;           // window bits (0 = choose from n)
   int task_len = 0;    // max sorted entries per accumulation task (0 = default)
-  bool dense = true;   // scalars uniform in Fr (H) vs NZCP witness mix (~1/3 full-width)
-  int precomp = 0;     // window precomputation factor (0 = default, 1 = none): see MsmInstance::pf
+  bool dense = true;   // scalars uniform in Fr (H) vs NZCP witness mix (~1/3 full-width, ~30 % equal to 1)
+  int precomp = 0;     // window precomputation factor of a single-section group (0 = auto, 1 = none): MsmGroup::pf
 };
 struct MsmWorkspace;   // opaque, msm.cuh
-// Fixed-base-set MSM instance: bases resident in HBM, infinity points compacted away.
-struct MsmInstance {
-  int curve = 1;               // 1 = G1, 2 = G2
-  uint32_t n = 0;              // non-infinity bases
-  void* d_bases = nullptr;     // Affine<F>[n] (Montgomery)
-  uint32_t* d_src = nullptr;   // scalar index of base i (into the scalar vector handed to run)
-  // Window precomputation: the base table also holds 2^(c W k) * P_i for k = 1..pf-1 (computed once at
-  // create), so scalar window j = k W + r of point i lands in row r as entry k n + i: only W = ceil(Ws / pf)
-  // rows of buckets are reduced instead of Ws, for the same number of bucket additions.
-  int c = 0, W = 0;            // window bits; ROWS of buckets (= output window sums, Horner on the host)
-  int Ws = 0;                  // scalar windows = ceil(256 / c)
-  uint32_t pf = 1;             // precomputation factor
-  uint32_t n_ext = 0;          // pf * n = entries per row = points in d_bases
-  uint32_t nbuckets = 0;       // per window = 2^(c-1)
-  uint32_t task_len = 0;
-  bool dense = true;           // MsmConfig::dense (the H-MSM)
+static constexpr int kMsmMaxSections = 3;
+// One base section handed to msm_group_create: n_total affine points in zkey file layout (64 B G1); infinity
+// points are compacted away.  bases2_host (optional) is the G2 twin of the SAME points (zkey section 7 next to
+// section 6: [v_i]G2 beside [v_i]G1): it rides on the section's sorted bucket lists (the "G2 lane").
+struct MsmSectionIn {
+  const uint8_t* bases_host = nullptr;   // G1 points (or nullptr for a G2-only group, see bases2_host)
+  const uint8_t* bases2_host = nullptr;  // G2 points (128 B)
+  uint32_t n_total = 0;
+  uint32_t scalar_offset = 0;            // scalar index of the section's first point
 };
-size_t msm_point_bytes(int curve);   // XYZZ bytes: 128 (G1) / 256 (G2)
-// bases_host: n_total affine points in file layout; keeps only non-infinity ones.
-int msm_instance_create(MsmInstance& m, int curve, const uint8_t* bases_host, uint32_t n_total,
-                        uint32_t scalar_offset, const MsmConfig& cfg);
-void msm_instance_destroy(MsmInstance& m);
-int msm_workspace_create(MsmWorkspace** ws, const MsmInstance* insts, int ninst);
+// A group of base sections that share ONE front end (digit extraction, bucket sort, task cut) over one scalar
+// vector: the witness MSMs A, B1, C (+ B2 riding on B1's buckets) are one group, the H-MSM another.  Bases stay
+// resident in HBM in the kernels' packed format.
+struct MsmGroup {
+  int nsec = 0;
+  uint32_t sec_n[kMsmMaxSections] = {0, 0, 0};       // non-infinity points per section
+  uint32_t sec_begin[kMsmMaxSections] = {0, 0, 0};   // their start in the concatenated point index space
+  uint32_t n = 0;                                    // total points
+  void* d_bases = nullptr;      // PackedAffine<G1>[pf * n], or nullptr (G2-only group)
+  void* d_bases2 = nullptr;     // PackedAffine<G2>[pf * sec_n[g2_sec]], or nullptr
+  int g2_sec = -1;              // section the G2 lane rides on
+  uint32_t* d_src = nullptr;    // [n] scalar index of point g
+  // Window precomputation (single-section groups): the base table also holds 2^(c W k) * P_i for k < pf, so
+  // scalar window j = k W + r of point i lands in row r as table entry k n + i; with pf = Ws (the dense H-MSM's
+  // default) ONE row of buckets collects every window and wider windows pay: c = 20 needs 13 additions per point
+  // instead of 16.
+  int c = 0, Ws = 0, W = 0;     // window bits; scalar windows ceil(254 / c); bucket rows of digit windows per section
+  uint32_t pf = 1;
+  uint32_t B = 0;               // buckets per row 2^(c-1)
+  uint32_t low_bits = 0, bins = 1;   // bucket = bin << low_bits | low: the two levels of the sort
+  bool ones = false;            // extra unweighted row per section for the scalars equal to 1 (witness groups)
+  uint32_t rps = 0, rows = 0;   // rows per section (W + ones), rows in total
+  uint32_t task_len = 0;
+  bool dense = true;
+  uint32_t chunks = 1, per = 0; // front-end geometry: workgroups over the points, points per workgroup
+  uint64_t max_entries = 0;     // upper bound on sorted entries of one launch
+};
+size_t msm_point_bytes(int curve);   // canonical XYZZ bytes: 128 (G1) / 256 (G2)
+int msm_group_create(MsmGroup& g, const MsmSectionIn* secs, int nsec, const MsmConfig& cfg);
+void msm_group_destroy(MsmGroup& g);
+int msm_workspace_create(MsmWorkspace** ws, const MsmGroup& g);
 void msm_workspace_destroy(MsmWorkspace* ws);
-// Runs the MSM of `m` against scalars d_scalars (standard form, 32 B each) and writes the W
-// per-window sums (XYZZ, Montgomery) to host memory out_windows: (W + 1) * msm_point_bytes, the
-// last entry being the unweighted sum of the scalar == 1 points (combine: msm_combine_windows below).
-float msm_last_accum_ms(const MsmWorkspace* ws);
-// accumulate kernel of the next msm_launch on `ws`: wait for `accum_gate` first (nullptr = none); persistent
-// grid of `waves_per_simd` wavefronts per SIMD (0 = full occupancy)
-void msm_set_schedule(MsmWorkspace* ws, hipEvent_t accum_gate, uint32_t waves_per_simd);
-hipEvent_t msm_sorted_event(MsmWorkspace* ws);       // recorded when the last launch's sorted task list is ready
-hipEvent_t msm_accum_done_event(MsmWorkspace* ws);   // recorded after the accumulate kernel of the last launch
-float msm_accum_event_offset_ms(MsmWorkspace* ws, hipEvent_t base, int which);   // G16_TRACE_HOST timeline
-int msm_run(const MsmInstance& m, MsmWorkspace* ws, const Fr* d_scalars, uint8_t* out_windows,
-            hipStream_t st);
-// The same split in two so several MSMs can be in flight on different streams: msm_launch only
-// enqueues (each MSM needs its own workspace), msm_collect waits for that stream and copies out.
-int msm_launch(const MsmInstance& m, MsmWorkspace* ws, const Fr* d_scalars, hipStream_t st);
-int msm_collect(MsmWorkspace* ws, uint8_t* out_windows, hipStream_t st);
+// Per-section results of one launch: XYZZ sums in the canonical Montgomery(2^256) image.
+struct MsmResult {
+  G1XYZZ g1[kMsmMaxSections];
+  G2XYZZ g2;
+};
+// msm_launch only enqueues: front end + G1 lane on `st`, the G2 lane (if any) forks onto `st2` after the sort
+// (st2 == nullptr or == st: same stream).  msm_collect waits for both, folds the window sums on the host
+// (Horner, c doublings per row) and fills `out`.  One launch in flight per workspace.
+int msm_launch(const MsmGroup& g, MsmWorkspace* ws, const Fr* d_scalars, hipStream_t st, hipStream_t st2);
+int msm_collect(const MsmGroup& g, MsmWorkspace* ws, MsmResult* out);
+float msm_last_accum_ms(const MsmWorkspace* ws, int lane);        // lane 0 = G1, 1 = G2: the accumulate kernel alone
+void msm_set_waves(MsmWorkspace* ws, uint32_t waves_per_simd);    // persistent accumulate grid (0 = full occupancy)
+float msm_event_offset_ms(MsmWorkspace* ws, hipEvent_t base, int lane, int which);   // G16_TRACE_HOST timeline
 
-// total = sum_j 2^(c j) * windows[j]  (Horner, c doublings per window) + windows[W] (ones window)
-template <class F> inline void msm_combine_windows(XYZZ<F>& total, const uint8_t* windows, int W, int c) {
+// total = sum_j 2^(c j) * windows[j]  (Horner, c doublings per window) [+ the unweighted ones row]
+template <class F> inline void msm_combine_windows(XYZZ<F>& total, const XYZZ<F>* windows, int W, int c, bool ones) {
   xyzz_set_inf(total);
   for (int j = W - 1; j >= 0; j--) {
     if (!xyzz_is_inf(total))
       for (int k = 0; k < c; k++) xyzz_dbl(total);
-    XYZZ<F> w;
-    memcpy(&w, windows + (size_t)j * sizeof(XYZZ<F>), sizeof(w));
-    xyzz_add(total, w);
+    xyzz_add(total, windows[j]);
   }
-  XYZZ<F> ones;
-  memcpy(&ones, windows + (size_t)W * sizeof(XYZZ<F>), sizeof(ones));
-  xyzz_add(total, ones);
+  if (ones) xyzz_add(total, windows[W]);
 }
-
 
 }  // namespace g16

@@ -1,4 +1,5 @@
-// G1 instantiation of the MSM kernels + the curve-independent host plumbing (instances, workspace).
+// MSM front end (curve independent: digit extraction, two-level bucket sort, scans, task queues), the G1 lane
+// instantiation, and the host plumbing of groups and workspaces.  See msm.cuh for the overall schedule.
 #include <string.h>
 
 #include "msm.cuh"
@@ -7,15 +8,435 @@ namespace g16 {
 
 size_t msm_point_bytes(int curve) { return curve == 2 ? sizeof(G2XYZZ) : sizeof(G1XYZZ); }
 
-int msm_convert_bases_g2(const void* in, void* out, uint32_t n);
+// ====================================================================== front-end kernels
+__device__ __forceinline__ uint32_t msm_extract(const uint32_t s[8], int pos, int c) {
+  const int word = pos >> 5, off = pos & 31;
+  if (word >= 8) return 0;
+  uint64_t v = s[word];
+  if (word + 1 < 8) v |= (uint64_t)s[word + 1] << 32;
+  return (uint32_t)(v >> off) & ((1u << c) - 1);
+}
+
+// Loads the scalar of point g, adds K; returns true when the scalar is exactly 1.
+__device__ __forceinline__ bool msm_load_scalar(const Fr* __restrict__ scalars, const uint32_t* __restrict__ src,
+                                                uint32_t g, const U256& K, uint32_t s[8]) {
+  const Fr x = scalars[src[g]];
+  uint32_t hi = 0;
+#pragma unroll
+  for (int k = 1; k < 8; k++) hi |= x.v[k];
+  const bool one = (hi == 0 && x.v[0] == 1);
+  uint64_t cy = 0;
+#pragma unroll
+  for (int k = 0; k < 8; k++) {
+    cy += (uint64_t)x.v[k] + K.v[k];
+    s[k] = (uint32_t)cy;
+    cy >>= 32;
+  }
+  return one;
+}
+
+// Pass 0 (MODE 0) counts, pass 1 (MODE 1) scatters the bucket entries of a chunk of points into (row, bin) runs.
+// A workgroup owns points [blockIdx.x * per, +per); its LDS holds one counter / cursor per (row, bin).  Signed
+// digit j of point i (section s) becomes the entry (table index | sign << 31, low bucket bits) in row
+// s * rps + (j mod W), bin = bucket >> low_bits; table index = global point index, or k n + i for window
+// j = k W + r of a precomputed table (single-section groups).  Lanes start at different windows so that the
+// LDS atomics of one instruction spread over the rows; the scalars equal to 1 -- a third of an NZCP witness, and
+// neighbours share their (row, bin) -- are counted with one atomic per wavefront and bin (ballot + popcount).
+// 256-thread workgroups on purpose: a 1024-thread workgroup needs 16 free wave slots on ONE CU at once and
+// starves behind the NTT's small workgroups when the two run concurrently (r02: 0.1 ms -> 3.5 ms).
+// hist layout: [rb][chunk] (chunk-contiguous, for the scan below).
+static constexpr uint32_t kBinThreads = 256;
+template <int MODE>
+static __global__ __launch_bounds__(kBinThreads) void msm_bin_pass_kernel(const Fr* __restrict__ scalars,
+                                                            const uint32_t* __restrict__ src, MsmPlan pl, U256 K,
+                                                            uint32_t per, uint32_t chunks, uint32_t* __restrict__ hist,
+                                                            const uint32_t* __restrict__ bin_start,
+                                                            uint2* __restrict__ tmp) {
+  extern __shared__ uint32_t lds[];
+  const uint32_t nrb = pl.rows * pl.bins;
+  for (uint32_t b = threadIdx.x; b < nrb; b += kBinThreads)
+    lds[b] = MODE ? bin_start[b] + hist[(size_t)b * chunks + blockIdx.x] : 0u;
+  __syncthreads();
+  const uint32_t lo = blockIdx.x * per;
+  const uint32_t hi = (lo + per < pl.n) ? lo + per : pl.n;
+  const uint32_t lowmask = (1u << pl.low_bits) - 1;
+  const uint32_t Ws = (uint32_t)pl.Ws;
+  const uint32_t lane = threadIdx.x & 63u;
+  const unsigned long long lt_mask = (1ull << lane) - 1;
+  for (uint32_t g0 = lo; g0 < hi; g0 += kBinThreads) {   // uniform trip count: the ballots below need every lane
+    const uint32_t g = g0 + threadIdx.x;
+    const bool live = g < hi;
+    uint32_t s = 0, i = 0, row0 = 0;
+    uint32_t sc[8];
+    bool one = false;
+    if (live) {
+      if (pl.nsec > 1 && g >= pl.sec_begin[1]) s = 1;
+      if (pl.nsec > 2 && g >= pl.sec_begin[2]) s = 2;
+      i = g - pl.sec_begin[s];
+      row0 = s * pl.rps;
+      one = msm_load_scalar(scalars, src, g, K, sc);
+    }
+    if (pl.ones) {
+      // wave-aggregated count of the ones: lanes with the same (row, bin) share one atomic
+      const bool is_one = live && one;
+      const uint32_t bucket = i & (pl.B - 1);
+      const uint32_t rb = (row0 + pl.W) * pl.bins + (bucket >> pl.low_bits);
+      unsigned long long todo = __ballot(is_one);
+      while (todo) {
+        const int leader = __ffsll((long long)todo) - 1;
+        const uint32_t key = (uint32_t)__shfl((int)rb, leader, 64);
+        const unsigned long long m = __ballot(is_one && rb == key) & todo;
+        uint32_t base = 0;
+        if ((int)lane == leader) base = atomicAdd(&lds[key], (uint32_t)__popcll(m));
+        base = (uint32_t)__shfl((int)base, leader, 64);
+        if (MODE && ((m >> lane) & 1ull)) tmp[base + (uint32_t)__popcll(m & lt_mask)] = make_uint2(g, bucket & lowmask);
+        todo &= ~m;
+      }
+    }
+    if (!live || (one && pl.ones)) continue;
+    uint32_t j = threadIdx.x % Ws;
+    for (uint32_t t = 0; t < Ws; t++) {
+      const uint32_t e = msm_extract(sc, (int)(j * (uint32_t)pl.c), pl.c);
+      const int32_t d = (j == Ws - 1) ? (int32_t)e : (int32_t)e - (int32_t)pl.B;   // the top window stays unsigned
+      if (d != 0) {
+        const uint32_t neg = d < 0 ? 1u : 0u;
+        const uint32_t bucket = (d < 0 ? (uint32_t)(-d) : (uint32_t)d) - 1u;
+        const uint32_t r = pl.pf > 1 ? j % pl.W : j;
+        const uint32_t eidx = pl.pf > 1 ? (j / pl.W) * pl.n + i : g;
+        const uint32_t rb = (row0 + r) * pl.bins + (bucket >> pl.low_bits);
+        const uint32_t pos = atomicAdd(&lds[rb], 1u);
+        if (MODE) tmp[pos] = make_uint2(eidx | (neg << 31), bucket & lowmask);
+      }
+      j = (j + 1 == Ws) ? 0u : j + 1;
+    }
+  }
+  if (!MODE) {
+    __syncthreads();
+    for (uint32_t b = threadIdx.x; b < nrb; b += kBinThreads) hist[(size_t)b * chunks + blockIdx.x] = lds[b];
+  }
+}
+
+// One wavefront per (row, bin): exclusive scan of its per-chunk counts in place (the run starts of pass 1,
+// relative to the bin's start), bin_cnt[rb] = the bin's total.
+static __global__ __launch_bounds__(64) void msm_bin_chunkscan_kernel(uint32_t* __restrict__ hist, uint32_t chunks,
+                                                               uint32_t* __restrict__ bin_cnt) {
+  const uint32_t rb = blockIdx.x, lane = threadIdx.x;
+  uint32_t* __restrict__ h = hist + (size_t)rb * chunks;
+  const uint32_t per = (chunks + 63) / 64;
+  const uint32_t lo = lane * per, hi = (lo + per < chunks) ? lo + per : chunks;
+  uint32_t s = 0;
+  for (uint32_t k = lo; k < hi; k++) s += h[k];
+  uint32_t inc = s;   // inclusive scan over lanes
+  for (int d = 1; d < 64; d <<= 1) {
+    const uint32_t v = (uint32_t)__shfl_up((int)inc, d, 64);
+    if ((int)lane >= d) inc += v;
+  }
+  uint32_t run = inc - s;
+  for (uint32_t k = lo; k < hi; k++) {
+    const uint32_t v = h[k];
+    h[k] = run;
+    run += v;
+  }
+  if (lane == 63) bin_cnt[rb] = inc;
+}
+// exclusive scan of bin_cnt[0, nrb) by one workgroup -> bin_start[0, nrb], bin_start[nrb] = total
+static __global__ __launch_bounds__(1024) void msm_bin_scan_kernel(const uint32_t* __restrict__ bin_cnt, uint32_t nrb,
+                                                            uint32_t* __restrict__ bin_start) {
+  __shared__ uint32_t sh[1024];
+  const uint32_t tid = threadIdx.x;
+  const uint32_t per = (nrb + 1023) / 1024;
+  const uint32_t lo = tid * per, hi = (lo + per < nrb) ? lo + per : nrb;
+  uint32_t s = 0;
+  for (uint32_t k = lo; k < hi; k++) s += bin_cnt[k];
+  sh[tid] = s;
+  __syncthreads();
+  for (uint32_t d = 1; d < 1024; d <<= 1) {
+    uint32_t v = 0;
+    if (tid >= d) v = sh[tid - d];
+    __syncthreads();
+    sh[tid] += v;
+    __syncthreads();
+  }
+  uint32_t run = sh[tid] - s;
+  for (uint32_t k = lo; k < hi; k++) {
+    const uint32_t v = bin_cnt[k];
+    bin_start[k] = run;
+    run += v;
+  }
+  if (tid == 1023) bin_start[nrb] = sh[1023];
+}
+
+// One workgroup per (row, bin): the bin's entries are one contiguous run of tmp.  Count the low bucket bits in
+// LDS, write the bucket populations, then scatter the table indices to the bin's OWN contiguous range of the
+// final list (second read of the run comes from L2).
+static constexpr uint32_t kMaxLowBits = 12;
+static __global__ __launch_bounds__(256) void msm_bin_sort_kernel(const uint2* __restrict__ tmp,
+                                                           const uint32_t* __restrict__ bin_start, MsmPlan pl,
+                                                           uint32_t* __restrict__ cnt, uint32_t* __restrict__ sorted) {
+  __shared__ uint32_t c[1u << kMaxLowBits];
+  __shared__ uint32_t part[256];
+  const uint32_t rb = blockIdx.x, tid = threadIdx.x;
+  const uint32_t lo = bin_start[rb], hi = bin_start[rb + 1];
+  const uint32_t nl = 1u << pl.low_bits;
+  const uint32_t row = rb / pl.bins, bin = rb % pl.bins;
+  uint32_t* __restrict__ cnt_out = cnt + (size_t)row * pl.B + ((size_t)bin << pl.low_bits);
+  if (lo == hi) {   // empty bin (e.g. the ones row of a dense scalar vector)
+    for (uint32_t l = tid; l < nl && ((bin << pl.low_bits) + l) < pl.B; l += 256) cnt_out[l] = 0;
+    return;
+  }
+  for (uint32_t l = tid; l < nl; l += 256) c[l] = 0;
+  __syncthreads();
+  {
+    uint32_t e = lo + tid;
+    for (; e + 768 < hi; e += 1024) {   // four independent loads in flight per lane
+      const uint32_t y0 = tmp[e].y, y1 = tmp[e + 256].y, y2 = tmp[e + 512].y, y3 = tmp[e + 768].y;
+      atomicAdd(&c[y0], 1u); atomicAdd(&c[y1], 1u); atomicAdd(&c[y2], 1u); atomicAdd(&c[y3], 1u);
+    }
+    for (; e < hi; e += 256) atomicAdd(&c[tmp[e].y], 1u);
+  }
+  __syncthreads();
+  // exclusive scan of c[0, nl): thread t owns nl / 256 consecutive counters (nl < 256: one each, rest idle)
+  const uint32_t per = (nl + 255) / 256;
+  const uint32_t l0 = tid * per, l1 = (l0 + per < nl) ? l0 + per : nl;
+  uint32_t s = 0;
+  for (uint32_t l = l0; l < l1; l++) s += c[l];
+  part[tid] = s;
+  __syncthreads();
+  for (uint32_t d = 1; d < 256; d <<= 1) {
+    uint32_t v = 0;
+    if (tid >= d) v = part[tid - d];
+    __syncthreads();
+    part[tid] += v;
+    __syncthreads();
+  }
+  uint32_t run = lo + part[tid] - s;
+  for (uint32_t l = l0; l < l1; l++) {
+    const uint32_t v = c[l];
+    if (((bin << pl.low_bits) + l) < pl.B) cnt_out[l] = v;
+    c[l] = run;
+    run += v;
+  }
+  __syncthreads();
+  {
+    uint32_t e = lo + tid;
+    for (; e + 768 < hi; e += 1024) {
+      const uint2 e0 = tmp[e], e1 = tmp[e + 256], e2 = tmp[e + 512], e3 = tmp[e + 768];
+      sorted[atomicAdd(&c[e0.y], 1u)] = e0.x;
+      sorted[atomicAdd(&c[e1.y], 1u)] = e1.x;
+      sorted[atomicAdd(&c[e2.y], 1u)] = e2.x;
+      sorted[atomicAdd(&c[e3.y], 1u)] = e3.x;
+    }
+    for (; e < hi; e += 256) {
+      const uint2 en = tmp[e];
+      sorted[atomicAdd(&c[en.y], 1u)] = en.x;
+    }
+  }
+}
+
+// Exclusive scans off = scan(cnt), toff = scan(ceil(cnt/task_len)), foff = scan(floor(cnt/task_len)) in three
+// launches: per-tile sums (2048 counters per workgroup) -> one workgroup scans the tile sums -> per-tile local
+// scan + tile offset.
+static constexpr uint32_t kScanTile = 2048;   // 256 threads x 8 counters
+
+static __global__ __launch_bounds__(256) void msm_scan_tiles_kernel(const uint32_t* __restrict__ cnt, uint32_t nb,
+                                                             uint32_t tl, uint32_t* __restrict__ tile_a,
+                                                             uint32_t* __restrict__ tile_b,
+                                                             uint32_t* __restrict__ tile_c) {
+  __shared__ uint32_t sh_a[256], sh_b[256], sh_c[256];
+  const uint32_t tid = threadIdx.x, base = blockIdx.x * kScanTile + tid * 8;
+  uint32_t sa = 0, sb = 0, sc = 0;
+#pragma unroll
+  for (int k = 0; k < 8; k++) {
+    const uint32_t v = (base + k < nb) ? cnt[base + k] : 0u;
+    sa += v;
+    sb += (v + tl - 1) / tl;
+    sc += v / tl;
+  }
+  sh_a[tid] = sa; sh_b[tid] = sb; sh_c[tid] = sc;
+  __syncthreads();
+  for (uint32_t d = 128; d > 0; d >>= 1) {
+    if (tid < d) { sh_a[tid] += sh_a[tid + d]; sh_b[tid] += sh_b[tid + d]; sh_c[tid] += sh_c[tid + d]; }
+    __syncthreads();
+  }
+  if (tid == 0) { tile_a[blockIdx.x] = sh_a[0]; tile_b[blockIdx.x] = sh_b[0]; tile_c[blockIdx.x] = sh_c[0]; }
+}
+
+// one workgroup; writes exclusive tile offsets in place and the totals
+static __global__ __launch_bounds__(1024) void msm_scan_top_kernel(uint32_t* __restrict__ tile_a,
+                                                            uint32_t* __restrict__ tile_b,
+                                                            uint32_t* __restrict__ tile_c, uint32_t ntiles,
+                                                            uint32_t* __restrict__ total_a,
+                                                            uint32_t* __restrict__ total_b,
+                                                            uint32_t* __restrict__ total_c) {
+  __shared__ uint32_t sh_a[1024], sh_b[1024], sh_c[1024];
+  const uint32_t tid = threadIdx.x;
+  const uint32_t chunk = (ntiles + 1023) / 1024;
+  const uint32_t lo = tid * chunk, hi = (lo + chunk < ntiles) ? lo + chunk : ntiles;
+  uint32_t sa = 0, sb = 0, sc = 0;
+  for (uint32_t k = lo; k < hi; k++) { sa += tile_a[k]; sb += tile_b[k]; sc += tile_c[k]; }
+  sh_a[tid] = sa; sh_b[tid] = sb; sh_c[tid] = sc;
+  __syncthreads();
+  for (uint32_t d = 1; d < 1024; d <<= 1) {
+    uint32_t va = 0, vb = 0, vc = 0;
+    if (tid >= d) { va = sh_a[tid - d]; vb = sh_b[tid - d]; vc = sh_c[tid - d]; }
+    __syncthreads();
+    sh_a[tid] += va; sh_b[tid] += vb; sh_c[tid] += vc;
+    __syncthreads();
+  }
+  uint32_t pa = sh_a[tid] - sa, pb = sh_b[tid] - sb, pc = sh_c[tid] - sc;
+  for (uint32_t k = lo; k < hi; k++) {
+    const uint32_t va = tile_a[k], vb = tile_b[k], vc = tile_c[k];
+    tile_a[k] = pa; tile_b[k] = pb; tile_c[k] = pc;
+    pa += va; pb += vb; pc += vc;
+  }
+  if (tid == 1023) { *total_a = sh_a[1023]; *total_b = sh_b[1023]; *total_c = sh_c[1023]; }
+}
+
+static __global__ __launch_bounds__(256) void msm_scan_apply_kernel(const uint32_t* __restrict__ cnt, uint32_t nb,
+                                                             uint32_t tl, const uint32_t* __restrict__ tile_a,
+                                                             const uint32_t* __restrict__ tile_b,
+                                                             const uint32_t* __restrict__ tile_c,
+                                                             uint32_t* __restrict__ off,
+                                                             uint32_t* __restrict__ toff,
+                                                             uint32_t* __restrict__ foff) {
+  __shared__ uint32_t sh_a[256], sh_b[256], sh_c[256];
+  const uint32_t tid = threadIdx.x, base = blockIdx.x * kScanTile + tid * 8;
+  uint32_t v[8], sa = 0, sb = 0, sc = 0;
+#pragma unroll
+  for (int k = 0; k < 8; k++) {
+    v[k] = (base + k < nb) ? cnt[base + k] : 0u;
+    sa += v[k];
+    sb += (v[k] + tl - 1) / tl;
+    sc += v[k] / tl;
+  }
+  sh_a[tid] = sa; sh_b[tid] = sb; sh_c[tid] = sc;
+  __syncthreads();
+  for (uint32_t d = 1; d < 256; d <<= 1) {
+    uint32_t va = 0, vb = 0, vc = 0;
+    if (tid >= d) { va = sh_a[tid - d]; vb = sh_b[tid - d]; vc = sh_c[tid - d]; }
+    __syncthreads();
+    sh_a[tid] += va; sh_b[tid] += vb; sh_c[tid] += vc;
+    __syncthreads();
+  }
+  uint32_t pa = tile_a[blockIdx.x] + sh_a[tid] - sa, pb = tile_b[blockIdx.x] + sh_b[tid] - sb,
+           pc = tile_c[blockIdx.x] + sh_c[tid] - sc;
+#pragma unroll
+  for (int k = 0; k < 8; k++) {
+    if (base + k < nb) {
+      off[base + k] = pa;
+      toff[base + k] = pb;
+      foff[base + k] = pc;
+    }
+    pa += v[k];
+    pb += (v[k] + tl - 1) / tl;
+    pc += v[k] / tl;
+  }
+}
+
+// ---------------------------------------------------------------------- task queues (per lane)
+// task descriptor = (first sorted entry, entry count); the tasks of one bucket have consecutive ids (their
+// partial sums are consecutive for the combine pass).  The work QUEUE is a permutation of the tasks: every
+// full-length task first, the remainders (one per bucket at most, shorter) after them -- the 64 lanes of a
+// wavefront then start and finish their full tasks in the same iteration, so the flush / start / request code
+// of the accumulate loop runs once per task instead of in nearly every iteration, and the queue ends with its
+// shortest tasks (a shorter drain).  qdesc[q] = (first entry, count, task id, -).  Task ids and queue positions
+// are relative to the lane's key range [key_lo, key_hi).
+__device__ __forceinline__ uint32_t msm_rem_class(uint32_t len, uint32_t task_len) {
+  return (len * kRemClasses) / task_len;      // len < task_len -> 0 .. kRemClasses - 1
+}
+
+// class_total[c] = number of remainder tasks (cnt % task_len != 0) of relative-length class c
+static __global__ __launch_bounds__(256) void msm_rem_count_kernel(const uint32_t* __restrict__ cnt, uint32_t key_lo,
+                                                            uint32_t key_hi, uint32_t tl,
+                                                            uint32_t* __restrict__ class_total) {
+  __shared__ uint32_t h[kRemClasses];
+  if (threadIdx.x < kRemClasses) h[threadIdx.x] = 0;
+  __syncthreads();
+  const uint32_t b = key_lo + blockIdx.x * blockDim.x + threadIdx.x;
+  if (b < key_hi) {
+    const uint32_t r = cnt[b] % tl;
+    if (r) atomicAdd(&h[msm_rem_class(r, tl)], 1u);
+  }
+  __syncthreads();
+  if (threadIdx.x < kRemClasses && h[threadIdx.x]) atomicAdd(&class_total[threadIdx.x], h[threadIdx.x]);
+}
+
+static __global__ __launch_bounds__(256) void msm_task_fill_kernel(const uint32_t* __restrict__ off,
+                                                            const uint32_t* __restrict__ toff,
+                                                            const uint32_t* __restrict__ foff, uint32_t key_lo,
+                                                            uint32_t key_hi, uint32_t task_len,
+                                                            uint2* __restrict__ task_desc, uint4* __restrict__ qdesc,
+                                                            const uint32_t* __restrict__ class_total,
+                                                            uint32_t* __restrict__ class_cursor) {
+  // remainders: after all the full tasks, by relative-length class (longest first) so that the lanes of a
+  // wavefront hold remainders of (nearly) equal length; inside a class the order is whatever the atomics give
+  __shared__ uint32_t h[kRemClasses], base[kRemClasses];
+  if (threadIdx.x < kRemClasses) h[threadIdx.x] = 0;
+  __syncthreads();
+  const uint32_t b = key_lo + blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t tb = toff[key_lo], fb = foff[key_lo];
+  uint32_t start = 0, left = 0, rem = 0, cls = 0, rank = 0;
+  if (b < key_hi) {
+    start = off[b];
+    left = off[b + 1] - start;
+    rem = left % task_len;
+    if (rem) {
+      cls = msm_rem_class(rem, task_len);
+      rank = atomicAdd(&h[cls], 1u);
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x < kRemClasses) {
+    const uint32_t c = threadIdx.x;
+    uint32_t before = foff[key_hi] - fb;                       // all full tasks, then the longer classes
+    for (uint32_t k = c + 1; k < kRemClasses; k++) before += class_total[k];
+    base[c] = h[c] ? before + atomicAdd(&class_cursor[c], h[c]) : 0u;
+  }
+  __syncthreads();
+  if (b >= key_hi) return;
+  uint32_t fq = foff[b] - fb;
+  for (uint32_t t = toff[b] - tb, e = toff[b + 1] - tb; t < e; t++) {
+    const uint32_t len = left < task_len ? left : task_len;
+    task_desc[t] = make_uint2(start, len);
+    qdesc[len == task_len ? fq++ : base[cls] + rank] = make_uint4(start, len, t, 0u);
+    start += len;
+    left -= len;
+  }
+}
+
+// ====================================================================== host side
+static void msm_make_K(int c, int Ws, U256& K) {
+  for (int i = 0; i < 8; i++) K.v[i] = 0;
+  for (int j = 0; j + 1 < Ws; j++) {
+    const int bit = c * j + c - 1;
+    if (bit < 256) K.v[bit >> 5] |= 1u << (bit & 31);
+  }
+}
+
+static MsmPlan msm_plan_of(const MsmGroup& g) {
+  MsmPlan pl{};
+  pl.nsec = (uint32_t)g.nsec;
+  pl.n = g.n;
+  for (int s = 0; s < kMsmMaxSections; s++) pl.sec_begin[s] = g.sec_begin[s];
+  pl.c = g.c;
+  pl.Ws = g.Ws;
+  pl.W = (uint32_t)g.W;
+  pl.pf = g.pf;
+  pl.B = g.B;
+  pl.low_bits = g.low_bits;
+  pl.bins = g.bins;
+  pl.rps = g.rps;
+  pl.rows = g.rows;
+  pl.ones = g.ones ? 1u : 0u;
+  return pl;
+}
+
 static int msm_convert_bases_g1(const void* in, void* out, uint32_t n) {
   msm_convert_bases_kernel<Fq29Ops><<<(n + 255) / 256, 256>>>((const G1Affine*)in, (PackedAffine<Fq29Ops>*)out, n);
   G16_HIP(hipGetLastError());
   G16_HIP(hipDeviceSynchronize());
   return G16_OK;
 }
-
-int msm_precompute_g2(const void* in, void* out, uint32_t n, int ndbl);
 static int msm_precompute_g1(const void* in, void* out, uint32_t n, int ndbl) {
   msm_precompute_kernel<FqOps><<<(n + 255) / 256, 256>>>((const G1Affine*)in, (G1Affine*)out, n, ndbl);
   G16_HIP(hipGetLastError());
@@ -23,232 +444,375 @@ static int msm_precompute_g1(const void* in, void* out, uint32_t n, int ndbl) {
   return G16_OK;
 }
 
-// window precomputation factor: MsmConfig::precomp, else G16_PRECOMP, else the default
-static uint32_t choose_pf(const MsmConfig& cfg, int Ws) {
-  int pf = cfg.precomp;
-  if (pf <= 0) {
-    const char* e = getenv("G16_PRECOMP");
-    pf = e ? atoi(e) : 1;
-  }
-  if (pf < 1) pf = 1;
-  if (pf > Ws) pf = Ws;
-  return (uint32_t)pf;
-}
-
-static int choose_c(uint32_t n) {
-  // minimise W * (n + 2.5 * 2^(c-1)) over c in [4, 16], W = ceil(256 / c).  For large n skip window
-  // sizes whose TOP window holds only 1..5 bits of the 254-bit scalar (c = 14, 12, 11, 10, 9, 7, 6, 4):
-  // its handful of buckets would each collect n / 2^bits entries (r01 sweep: c = 14 made the H-MSM 3x
-  // slower).  c = 16 (14 top bits), 15 (top window empty), 13 (7 bits) and 8 (6 bits) remain.
-  int best = 16;
+// Window bits.  Without precomputation: minimise Ws * (n + 2.5 * 2^(c-1)) over c, skipping window sizes whose
+// TOP window holds only 1..5 bits of the 254-bit scalar (its handful of buckets would each collect n / 2^bits
+// entries: r01 sweep, c = 14 made the H-MSM 3x slower).  With full precomputation (one row of buckets):
+// minimise Ws * n + 2.5 * 2^(c-1); the crowded top-window buckets are cut into tasks like any other.
+static int choose_c(uint32_t n, bool full_precomp) {
+  int best = 13;
   double best_cost = 1e300;
-  for (int c = 4; c <= 16; c++) {
-    const int W = (256 + c - 1) / c;
-    const int top_bits = 254 - c * (W - 1);
+  for (int c = 4; c <= (full_precomp ? 21 : 16); c++) {
+    const int Ws = (255 + c - 1) / c;
+    const int top_bits = 254 - c * (Ws - 1);
     if (n >= 4096 && top_bits > 0 && top_bits < 6) continue;
-    const double cost = (double)W * ((double)n + 2.5 * (double)(1u << (c - 1)));
+    const double cost = full_precomp ? (double)Ws * (double)n + 2.5 * (double)(1u << (c - 1))
+                                     : (double)Ws * ((double)n + 2.5 * (double)(1u << (c - 1)));
     if (cost < best_cost) { best_cost = cost; best = c; }
   }
   return best;
 }
 
-int msm_instance_create(MsmInstance& m, int curve, const uint8_t* bases_host, uint32_t n_total,
-                        uint32_t scalar_offset, const MsmConfig& cfg) {
-  const size_t psz = curve == 2 ? sizeof(G2Affine) : sizeof(G1Affine);
-  m.curve = curve;
-  m.dense = cfg.dense;
+static bool is_inf_bytes(const uint8_t* p, size_t psz) {
+  for (size_t k = 0; k < psz; k += 8) {
+    uint64_t w;
+    memcpy(&w, p + k, 8);
+    if (w) return false;
+  }
+  return true;
+}
+
+// upload `count` canonical affine points, convert to the packed lazy format, and (pf > 1) append the levels
+// 2^(ndbl k) * P: dst holds pf * count packed points, level-major
+static int upload_table(int curve, const std::vector<uint8_t>& canon, uint32_t count, uint32_t pf, int ndbl, void** dst) {
+  const size_t lazy_pt = curve == 2 ? sizeof(PackedAffine<Fq2x29Ops>) : sizeof(PackedAffine<Fq29Ops>);
+  void* tmp = nullptr;
+  void* tmp2 = nullptr;
+  G16_HIP(hipMalloc(&tmp, canon.size()));
+  if (pf > 1) G16_HIP(hipMalloc(&tmp2, canon.size()));
+  G16_HIP(hipMalloc(dst, (size_t)pf * count * lazy_pt));
+  G16_HIP(hipMemcpy(tmp, canon.data(), canon.size(), hipMemcpyHostToDevice));
+  int rc = G16_OK;
+  for (uint32_t k = 0; k < pf && !rc; k++) {
+    void* cur = (k & 1) ? tmp2 : tmp;
+    void* nxt = (k & 1) ? tmp : tmp2;
+    void* d = (uint8_t*)*dst + (size_t)k * count * lazy_pt;
+    rc = curve == 2 ? msm_convert_bases_g2(cur, d, count) : msm_convert_bases_g1(cur, d, count);
+    if (!rc && k + 1 < pf) rc = curve == 2 ? msm_precompute_g2(cur, nxt, count, ndbl) : msm_precompute_g1(cur, nxt, count, ndbl);
+  }
+  (void)hipFree(tmp);
+  if (tmp2) (void)hipFree(tmp2);
+  return rc;
+}
+
+int msm_group_create(MsmGroup& g, const MsmSectionIn* secs, int nsec, const MsmConfig& cfg) {
+  if (nsec < 1 || nsec > kMsmMaxSections) { set_error("msm: 1..3 sections per group"); return G16_E_ARG; }
+  g = MsmGroup();
+  g.nsec = nsec;
+  g.dense = cfg.dense;
+  bool has_g1 = false;
+  int g2_sec = -1;
+  for (int s = 0; s < nsec; s++) {
+    if (secs[s].bases_host) has_g1 = true;
+    if (secs[s].bases2_host) {
+      if (g2_sec >= 0) { set_error("msm: one G2 lane per group"); return G16_E_ARG; }
+      g2_sec = s;
+    }
+    if (!secs[s].bases_host && !secs[s].bases2_host) { set_error("msm: section without bases"); return G16_E_ARG; }
+  }
+  if (has_g1)
+    for (int s = 0; s < nsec; s++)
+      if (!secs[s].bases_host) { set_error("msm: a G2-only section cannot share a group with G1 sections"); return G16_E_ARG; }
+  // compaction: a point is kept when it is not infinity (both twins agree in any well-formed key; a point that
+  // is infinity in exactly one of the two tables is rejected -- the caller then builds two separate groups)
   std::vector<uint32_t> src;
-  std::vector<uint8_t> packed;
-  src.reserve(n_total);
-  packed.reserve((size_t)n_total * psz);
-  for (uint32_t i = 0; i < n_total; i++) {
-    const uint8_t* p = bases_host + (size_t)i * psz;
-    bool inf = true;
-    for (size_t k = 0; k < psz; k += 8) {
-      uint64_t w;
-      memcpy(&w, p + k, 8);
-      if (w) { inf = false; break; }
+  std::vector<uint8_t> canon1, canon2;
+  uint64_t total = 0;
+  for (int s = 0; s < nsec; s++) total += secs[s].n_total;
+  src.reserve(total);
+  for (int s = 0; s < nsec; s++) {
+    const MsmSectionIn& in = secs[s];
+    g.sec_begin[s] = (uint32_t)src.size();
+    for (uint32_t i = 0; i < in.n_total; i++) {
+      const bool inf1 = in.bases_host ? is_inf_bytes(in.bases_host + (size_t)i * 64, 64) : true;
+      const bool inf2 = in.bases2_host ? is_inf_bytes(in.bases2_host + (size_t)i * 128, 128) : true;
+      if (in.bases_host && in.bases2_host && inf1 != inf2) {
+        set_error("msm: G1/G2 twin sections disagree on a point at infinity");
+        return G16_E_FORMAT;
+      }
+      if (in.bases_host ? inf1 : inf2) continue;
+      src.push_back(in.scalar_offset + i);
+      if (in.bases_host) canon1.insert(canon1.end(), in.bases_host + (size_t)i * 64, in.bases_host + (size_t)i * 64 + 64);
+      if (in.bases2_host) canon2.insert(canon2.end(), in.bases2_host + (size_t)i * 128, in.bases2_host + (size_t)i * 128 + 128);
     }
-    if (inf) continue;
-    src.push_back(scalar_offset + i);
-    packed.insert(packed.end(), p, p + psz);
+    g.sec_n[s] = (uint32_t)src.size() - g.sec_begin[s];
   }
-  m.n = (uint32_t)src.size();
-  if (m.n >= 0x7fffffffu) { set_error("msm: too many bases"); return G16_E_ARG; }
-  // witness MSMs: only ~1/3 of the scalars are full-width -> size the windows for that
-  const uint32_t n_eff = cfg.dense ? m.n : m.n / 3 + 1;
-  m.c = cfg.c ? cfg.c : choose_c(n_eff ? n_eff : 1);
-  if (m.c < 2 || m.c > 16) { set_error("msm: window bits must be in [2,16]"); return G16_E_ARG; }
-  m.Ws = (256 + m.c - 1) / m.c;
-  m.pf = choose_pf(cfg, m.Ws);
-  m.W = (m.Ws + (int)m.pf - 1) / (int)m.pf;
-  m.pf = (uint32_t)((m.Ws + m.W - 1) / m.W);   // drop empty trailing levels (Ws = 16, pf = 5 -> W = 4, pf = 4)
-  m.n_ext = m.pf * m.n;
-  if ((uint64_t)m.pf * m.n >= 0x7fffffffull) { set_error("msm: too many precomputed bases"); return G16_E_ARG; }
-  m.nbuckets = 1u << (m.c - 1);
-  // Task length: enough tasks to fill ~256k lanes (256 CUs x 4 SIMDs x 4 waves x 64), within [16, 256].
+  for (int s = nsec; s < kMsmMaxSections; s++) g.sec_begin[s] = (uint32_t)src.size();
+  g.n = (uint32_t)src.size();
+  if (g2_sec >= 0 && g.sec_n[g2_sec] == 0) g2_sec = -1;   // nothing rides: the G2 sum is the point at infinity
+  g.g2_sec = g2_sec;
+  if (g.n >= 0x40000000u) { set_error("msm: too many bases"); return G16_E_ARG; }
+  // ---- geometry
+  // witness groups: only ~1/3 of the scalars are full-width -> size the windows for that
+  uint32_t n_max = 0;
+  for (int s = 0; s < nsec; s++) n_max = g.sec_n[s] > n_max ? g.sec_n[s] : n_max;
+  const uint32_t n_eff = cfg.dense ? n_max : n_max / 3 + 1;
+  int pf_req = cfg.precomp;
+  if (pf_req <= 0) {
+    const char* e = getenv("G16_PRECOMP");
+    pf_req = e ? atoi(e) : 0;
+  }
+  // default: full window precomputation for a dense single-section group that is large enough to pay for its
+  // table (Ws x 64 B per point, e.g. 1.75 GB for the 2^21-point H section; capped at 8 GiB)
+  bool full = false;
+  if (nsec == 1 && g.n > 0) {
+    if (pf_req == 0) full = cfg.dense && g.n >= (1u << 15);
+    else if (pf_req >= 255) full = true;
+  }
+  g.c = cfg.c ? cfg.c : choose_c(n_eff ? n_eff : 1, full);
+  // witness groups: c = 15/16 would minimise the addition count by a few percent, but every bucket costs scan,
+  // queue and reduce work on the latency-bound part of the chain: stay at <= 13 (4096 buckets per row)
+  if (!cfg.c && !cfg.dense && g.c > 13) g.c = 13;
+  if (g.c < 2 || g.c > 22) { set_error("msm: window bits must be in [2,22]"); return G16_E_ARG; }
+  // scalar windows: the top one stays unsigned and must fit the buckets: 254 - c (Ws - 1) <= c - 1
+  g.Ws = (255 + g.c - 1) / g.c;
+  uint32_t pf = 1;
+  if (nsec == 1) {
+    if (full) pf = (uint32_t)g.Ws;
+    else if (pf_req > 1) pf = (uint32_t)pf_req;
+    if (pf > (uint32_t)g.Ws) pf = (uint32_t)g.Ws;
+    const size_t pt = (g2_sec >= 0 && !has_g1) ? 128 : 64;
+    while (pf > 1 && (uint64_t)pf * g.n * pt > (8ull << 30)) pf--;
+  }
+  g.W = (g.Ws + (int)pf - 1) / (int)pf;
+  g.pf = (uint32_t)((g.Ws + g.W - 1) / g.W);   // drop empty trailing levels (Ws = 16, pf = 5 -> W = 4, pf = 4)
+  if ((uint64_t)g.pf * g.n >= 0x7fffffffull) { set_error("msm: too many precomputed bases"); return G16_E_ARG; }
+  g.B = 1u << (g.c - 1);
+  g.ones = !cfg.dense;
+  g.rps = (uint32_t)g.W + (g.ones ? 1u : 0u);
+  g.rows = (uint32_t)nsec * g.rps;
+  // two-level sort: bucket = bin << low_bits | low; 8 low bits unless that leaves too many (row, bin) counters
+  // for the LDS of the binning passes (<= 12288)
+  g.low_bits = (uint32_t)(g.c - 1) < 8u ? (uint32_t)(g.c - 1) : 8u;
+  while (g.low_bits < kMaxLowBits && (uint64_t)g.rows * (g.B >> g.low_bits) > 12288) g.low_bits++;
+  g.bins = g.B >> g.low_bits;
+  if ((uint64_t)g.rows * g.bins > 12288) { set_error("msm: window bits too large for this group"); return G16_E_ARG; }
+  // Task length: enough tasks to fill ~256k lanes (256 CUs x 4 SIMDs x 4 waves x 64), within [16, 32]: short
+  // tasks keep the drain tail of the persistent kernel small (sweep r01)
   if (cfg.task_len) {
-    m.task_len = (uint32_t)cfg.task_len;
+    g.task_len = (uint32_t)cfg.task_len;
   } else {
-    const uint64_t entries = (uint64_t)n_eff * m.Ws;
-    uint64_t t = entries / 262144;
-    m.task_len = (uint32_t)(t < 16 ? 16 : (t > 32 ? 32 : t));   // short tasks: small drain tail (sweep r01)
+    const uint64_t entries = (uint64_t)n_eff * g.Ws * (uint32_t)nsec;
+    const uint64_t t = entries / 262144;
+    g.task_len = (uint32_t)(t < 16 ? 16 : (t > 32 ? 32 : t));
   }
-  if (m.n) {
-    // upload the canonical image, convert once on the device to the kernels' 9x29 representation
-    void* tmp = nullptr;
-    void* tmp2 = nullptr;
-    const size_t lazy_pt = curve == 2 ? sizeof(PackedAffine<Fq2x29Ops>) : sizeof(PackedAffine<Fq29Ops>);
-    G16_HIP(hipMalloc(&tmp, packed.size()));
-    if (m.pf > 1) G16_HIP(hipMalloc(&tmp2, packed.size()));
-    G16_HIP(hipMalloc(&m.d_bases, (size_t)m.n_ext * lazy_pt));
-    G16_HIP(hipMalloc(&m.d_src, (size_t)m.n * 4));
-    G16_HIP(hipMemcpy(tmp, packed.data(), packed.size(), hipMemcpyHostToDevice));
-    G16_HIP(hipMemcpy(m.d_src, src.data(), (size_t)m.n * 4, hipMemcpyHostToDevice));
-    int rc = G16_OK;
-    for (uint32_t k = 0; k < m.pf && !rc; k++) {
-      // level k = 2^(c W) * level k-1 (canonical, ping-pong between tmp and tmp2), then to the lazy format
-      void* cur = (k & 1) ? tmp2 : tmp;
-      void* nxt = (k & 1) ? tmp : tmp2;
-      void* dst = (uint8_t*)m.d_bases + (size_t)k * m.n * lazy_pt;
-      rc = curve == 2 ? msm_convert_bases_g2(cur, dst, m.n) : msm_convert_bases_g1(cur, dst, m.n);
-      if (!rc && k + 1 < m.pf)
-        rc = curve == 2 ? msm_precompute_g2(cur, nxt, m.n, m.c * m.W) : msm_precompute_g1(cur, nxt, m.n, m.c * m.W);
-    }
-    (void)hipFree(tmp);
-    if (tmp2) (void)hipFree(tmp2);
-    if (rc) return rc;
+  g.max_entries = (uint64_t)g.n * (uint32_t)g.Ws;
+  if (g.max_entries >= 0x7fffffffull) { set_error("msm: too many bucket entries"); return G16_E_ARG; }
+  // front-end chunks: >= 4096 points per 256-thread workgroup (long (row, bin) runs), at most 1024 workgroups
+  {
+    uint32_t per = 4096;
+    if (const char* e = getenv("G16_BIN_PER")) per = (uint32_t)atoi(e) >= 256 ? (uint32_t)atoi(e) : 256;
+    uint64_t chunks = ((uint64_t)g.n + per - 1) / per;
+    if (chunks > 1024) chunks = 1024;
+    if (chunks < 1) chunks = 1;
+    g.chunks = (uint32_t)chunks;
+    g.per = (uint32_t)(((uint64_t)g.n + chunks - 1) / chunks);
+    if (g.per == 0) g.per = 1;
   }
+  if (g.n == 0) return G16_OK;
+  // ---- resident tables
+  G16_HIP(hipMalloc(&g.d_src, (size_t)g.n * 4));
+  G16_HIP(hipMemcpy(g.d_src, src.data(), (size_t)g.n * 4, hipMemcpyHostToDevice));
+  int rc = G16_OK;
+  if (has_g1) rc = upload_table(1, canon1, g.n, g.pf, g.c * g.W, &g.d_bases);
+  if (!rc && g2_sec >= 0) rc = upload_table(2, canon2, g.sec_n[g2_sec], g.pf, g.c * g.W, &g.d_bases2);
+  return rc;
+}
+
+void msm_group_destroy(MsmGroup& g) {
+  if (g.d_bases) (void)hipFree(g.d_bases);
+  if (g.d_bases2) (void)hipFree(g.d_bases2);
+  if (g.d_src) (void)hipFree(g.d_src);
+  g.d_bases = g.d_bases2 = nullptr;
+  g.d_src = nullptr;
+  g.n = 0;
+}
+
+static int lane_create(MsmLaneWs& ln, const MsmGroup& g, int curve, uint32_t key_lo, uint32_t key_hi, uint32_t point_base,
+                       uint64_t entries) {
+  ln.active = true;
+  ln.curve = curve;
+  ln.key_lo = key_lo;
+  ln.key_hi = key_hi;
+  ln.point_base = point_base;
+  ln.rows = (key_hi - key_lo) / g.B;
+  const uint64_t nbk = (uint64_t)key_hi - key_lo;
+  // every non-empty bucket has <= 1 short task + entries / task_len full ones
+  ln.max_tasks = nbk + entries / g.task_len + 64;
+  const size_t pb = curve == 2 ? sizeof(G2XYZZ29) : sizeof(G1XYZZ29);   // device-side (lazy) points
+  const size_t cpb = msm_point_bytes(curve);                             // canonical, host-visible
+  const uint32_t sl = msm_seg_len(true) < msm_seg_len(false) ? msm_seg_len(true) : msm_seg_len(false);
+  const uint64_t nseg = (g.B + sl - 1) / sl;
+  G16_HIP(hipMalloc(&ln.d_task_desc, (ln.max_tasks + 1) * sizeof(uint2)));
+  G16_HIP(hipMalloc(&ln.d_qdesc, (ln.max_tasks + 1) * sizeof(uint4)));
+  G16_HIP(hipMalloc(&ln.d_class, 2 * kRemClasses * 4));
+  G16_HIP(hipMalloc(&ln.d_queue, 64));
+  G16_HIP(hipMalloc(&ln.d_redo, (ln.max_tasks + 1) * 4));
+  G16_HIP(hipMalloc(&ln.d_partial, ln.max_tasks * pb + 256));
+  G16_HIP(hipMalloc(&ln.d_bsum, nbk * pb + 256));
+  ln.max_heavy = (uint32_t)(ln.max_tasks / kLightTasks + 16);
+  G16_HIP(hipMalloc(&ln.d_heavy, ((size_t)ln.max_heavy + 2) * 4));
+  G16_HIP(hipMalloc(&ln.d_seg, (size_t)ln.rows * nseg * pb + 256));
+  G16_HIP(hipMalloc(&ln.d_red, 2 * (size_t)ln.rows * ((nseg + 63) / 64) * pb + 256));
+  ln.out_bytes = (size_t)ln.rows * cpb;
+  G16_HIP(hipHostMalloc((void**)&ln.h_pinned, ln.out_bytes + 256));
+  G16_HIP(hipMalloc(&ln.d_canon, ln.out_bytes + 256));
+  G16_HIP(hipEventCreate(&ln.ev0));
+  G16_HIP(hipEventCreate(&ln.ev1));
+  G16_HIP(hipEventCreate(&ln.ev_done));
   return G16_OK;
 }
 
-void msm_instance_destroy(MsmInstance& m) {
-  if (m.d_bases) (void)hipFree(m.d_bases);
-  if (m.d_src) (void)hipFree(m.d_src);
-  m.d_bases = nullptr;
-  m.d_src = nullptr;
-  m.n = 0;
+static void lane_destroy(MsmLaneWs& ln) {
+  void* ptrs[] = {ln.d_task_desc, ln.d_qdesc, ln.d_class, ln.d_queue, ln.d_redo, ln.d_partial, ln.d_bsum, ln.d_heavy,
+                  ln.d_seg, ln.d_red, ln.d_canon};
+  for (void* p : ptrs)
+    if (p) (void)hipFree(p);
+  if (ln.h_pinned) (void)hipHostFree(ln.h_pinned);
+  hipEvent_t evs[] = {ln.ev0, ln.ev1, ln.ev_done, ln.trace_ev[0], ln.trace_ev[1], ln.trace_ev[2], ln.trace_ev[3]};
+  for (hipEvent_t e : evs)
+    if (e) (void)hipEventDestroy(e);
+  ln = MsmLaneWs();
 }
 
-int msm_workspace_create(MsmWorkspace** out, const MsmInstance* insts, int ninst) {
+int msm_workspace_create(MsmWorkspace** out, const MsmGroup& g) {
   MsmWorkspace* ws = new MsmWorkspace();
-  size_t part_bytes = 0, seg_bytes = 0, red_bytes = 0, pin_bytes = 0, bsum_bytes = 0;
-  for (int i = 0; i < ninst; i++) {
-    const MsmInstance& m = insts[i];
-    const uint64_t nb = (uint64_t)(m.W + 1) * m.nbuckets;   // + the ones window
-    const uint64_t entries = (uint64_t)m.n * m.Ws;
-    const uint64_t tasks = nb + entries / (m.task_len >= 16 ? m.task_len / 4 : 4) + 64;   // worst case of the graded lengths
-    const uint32_t sl = msm_seg_len(true) < msm_seg_len(false) ? msm_seg_len(true) : msm_seg_len(false);   // the shorter: more segments
-    const uint64_t nseg = (m.nbuckets + sl - 1) / sl;
-    const size_t pb = m.curve == 2 ? sizeof(G2XYZZ29) : sizeof(G1XYZZ29);   // device-side (lazy) points
-    const size_t cpb = msm_point_bytes(m.curve);                             // canonical, host-visible
-    if (entries > ws->max_entries) ws->max_entries = (uint32_t)entries;
-    if (nb > ws->max_buckets) ws->max_buckets = (uint32_t)nb;
-    if (tasks > ws->max_tasks) ws->max_tasks = (uint32_t)tasks;
-    if (tasks * pb > part_bytes) part_bytes = tasks * pb;
-    if (nb * pb > bsum_bytes) bsum_bytes = nb * pb;
-    if ((m.W + 1) * nseg * pb > seg_bytes) seg_bytes = (m.W + 1) * nseg * pb;
-    const size_t rb = 2 * (size_t)(m.W + 1) * ((nseg + 63) / 64) * pb;
-    if (rb > red_bytes) red_bytes = rb;
-    if ((size_t)(m.W + 1) * cpb > pin_bytes) pin_bytes = (size_t)(m.W + 1) * cpb;
-  }
   *out = ws;
-  // sort geometry: ~4 workgroups of 1024 threads per CU when the LDS histogram allows it
-  size_t dig_words = 0, hist_words = 0;
-  for (int i = 0; i < ninst; i++) {
-    const MsmInstance& m = insts[i];
-    const uint32_t WT = (uint32_t)m.W + 1;
-    const size_t lds = (size_t)m.nbuckets * 4;
-    uint32_t per_cu = (uint32_t)(160 * 1024 / (lds ? lds : 1));
-    if (per_cu > 2) per_cu = 2;        // 1024-thread workgroups: at most 2 per CU
-    if (per_cu < 1) per_cu = 1;
-    uint32_t chunks = (256 * per_cu + WT - 1) / WT;
-    const uint32_t max_chunks = m.n_ext / 4096 + 1;
-    if (chunks > max_chunks) chunks = max_chunks;
-    if (chunks > ws->chunks) ws->chunks = chunks;
-    if ((size_t)WT * m.n_ext > dig_words) dig_words = (size_t)WT * m.n_ext;
-    if ((size_t)WT * chunks * m.nbuckets > hist_words) hist_words = (size_t)WT * chunks * m.nbuckets;
-  }
-  G16_HIP(hipMalloc(&ws->d_dig, (dig_words + 4) * 4));
-  G16_HIP(hipMalloc(&ws->d_hist, (hist_words + 4) * 4));
-  G16_HIP(hipMalloc(&ws->d_cnt, ((size_t)ws->max_buckets + 1) * 4));
-  G16_HIP(hipMalloc(&ws->d_off, ((size_t)ws->max_buckets + 1) * 4));
-  G16_HIP(hipMalloc(&ws->d_toff, ((size_t)ws->max_buckets + 1) * 4));
-  G16_HIP(hipMalloc(&ws->d_sorted, ((size_t)ws->max_entries + 1) * 4));
-  G16_HIP(hipMalloc(&ws->d_task_desc, ((size_t)ws->max_tasks + 1) * sizeof(uint2)));
-  G16_HIP(hipMalloc(&ws->d_qdesc, ((size_t)ws->max_tasks + 1) * sizeof(uint4)));
-  G16_HIP(hipMalloc(&ws->d_foff, ((size_t)ws->max_buckets + 1) * 4));
-  G16_HIP(hipMalloc(&ws->d_tile_c, ((size_t)ws->max_buckets / kScanTile + 2) * 4));
-  G16_HIP(hipMalloc(&ws->d_class, 2 * 32 * 4));
-  G16_HIP(hipMalloc(&ws->d_queue, 64));
-  G16_HIP(hipMalloc(&ws->d_redo, ((size_t)ws->max_tasks + 1) * 4));
-  G16_HIP(hipMalloc(&ws->d_tile_a, ((size_t)ws->max_buckets / kScanTile + 2) * 4));
-  G16_HIP(hipMalloc(&ws->d_tile_b, ((size_t)ws->max_buckets / kScanTile + 2) * 4));
-  G16_HIP(hipMalloc(&ws->d_partial, part_bytes + 256));
-  G16_HIP(hipMalloc(&ws->d_bsum, bsum_bytes + 256));
-  ws->max_heavy = ws->max_tasks / kLightTasks + 16;
-  G16_HIP(hipMalloc(&ws->d_heavy, ((size_t)ws->max_heavy + 2) * 4));
-  G16_HIP(hipMalloc(&ws->d_seg, seg_bytes + 256));
-  G16_HIP(hipMalloc(&ws->d_red, red_bytes + 256));
-  G16_HIP(hipHostMalloc((void**)&ws->h_pinned, pin_bytes + 256));
-  G16_HIP(hipMalloc(&ws->d_canon, pin_bytes + 256));
-  G16_HIP(hipEventCreate(&ws->ev0));
-  G16_HIP(hipEventCreate(&ws->ev1));
+  if (g.n == 0) return G16_OK;
+  const uint32_t nrb = g.rows * g.bins;
+  ws->nb = g.rows * g.B;
+  const size_t ntiles = (size_t)ws->nb / kScanTile + 2;
+  G16_HIP(hipMalloc(&ws->d_hist, ((size_t)g.chunks * nrb + 4) * 4));
+  G16_HIP(hipMalloc(&ws->d_bin_cnt, ((size_t)nrb + 4) * 4));
+  G16_HIP(hipMalloc(&ws->d_bin_start, ((size_t)nrb + 4) * 4));
+  G16_HIP(hipMalloc(&ws->d_tmp, (g.max_entries + 4) * sizeof(uint2)));
+  G16_HIP(hipMalloc(&ws->d_sorted, (g.max_entries + 4) * 4));
+  G16_HIP(hipMalloc(&ws->d_cnt, ((size_t)ws->nb + 4) * 4));
+  G16_HIP(hipMalloc(&ws->d_off, ((size_t)ws->nb + 4) * 4));
+  G16_HIP(hipMalloc(&ws->d_toff, ((size_t)ws->nb + 4) * 4));
+  G16_HIP(hipMalloc(&ws->d_foff, ((size_t)ws->nb + 4) * 4));
+  G16_HIP(hipMalloc(&ws->d_tile_a, ntiles * 4));
+  G16_HIP(hipMalloc(&ws->d_tile_b, ntiles * 4));
+  G16_HIP(hipMalloc(&ws->d_tile_c, ntiles * 4));
   G16_HIP(hipEventCreate(&ws->ev_sorted));
-  return G16_OK;
+  int rc = G16_OK;
+  if (g.d_bases) rc = lane_create(ws->lane[0], g, 1, 0, ws->nb, 0, g.max_entries);
+  if (!rc && g.g2_sec >= 0) {
+    const uint32_t lo = (uint32_t)g.g2_sec * g.rps * g.B;
+    rc = lane_create(ws->lane[1], g, 2, lo, lo + g.rps * g.B, g.pf > 1 ? 0u : g.sec_begin[g.g2_sec],
+                     (uint64_t)g.sec_n[g.g2_sec] * (uint32_t)g.Ws);
+  }
+  return rc;
 }
 
 void msm_workspace_destroy(MsmWorkspace* ws) {
   if (!ws) return;
-  void* ptrs[] = {ws->d_cnt, ws->d_off, ws->d_toff, ws->d_sorted, ws->d_task_desc, ws->d_queue, ws->d_tile_a, ws->d_tile_b,
-                  ws->d_partial, ws->d_seg, ws->d_red, ws->d_bsum, ws->d_heavy, ws->d_dig, ws->d_hist, ws->d_canon, ws->d_redo,
-                  ws->d_qdesc, ws->d_foff, ws->d_tile_c, ws->d_class};
+  void* ptrs[] = {ws->d_hist, ws->d_bin_cnt, ws->d_bin_start, ws->d_tmp, ws->d_sorted, ws->d_cnt, ws->d_off, ws->d_toff,
+                  ws->d_foff, ws->d_tile_a, ws->d_tile_b, ws->d_tile_c};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
-  if (ws->h_pinned) (void)hipHostFree(ws->h_pinned);
-  if (ws->ev0) (void)hipEventDestroy(ws->ev0);
-  if (ws->ev1) (void)hipEventDestroy(ws->ev1);
+  for (auto& ln : ws->lane) lane_destroy(ln);
   if (ws->ev_sorted) (void)hipEventDestroy(ws->ev_sorted);
+  for (hipEvent_t e : ws->trace_ev)
+    if (e) (void)hipEventDestroy(e);
   delete ws;
 }
 
-int msm_launch_g2(const MsmInstance& m, MsmWorkspace* ws, const Fr* d_scalars, hipStream_t st);
-
-float msm_last_accum_ms(const MsmWorkspace* ws) { return ws->last_accum_ms; }
-void msm_set_schedule(MsmWorkspace* ws, hipEvent_t accum_gate, uint32_t waves_per_simd) {
-  ws->accum_gate = accum_gate;
-  ws->waves_per_simd = waves_per_simd;
-}
-hipEvent_t msm_accum_done_event(MsmWorkspace* ws) { return ws->ev1; }
-hipEvent_t msm_sorted_event(MsmWorkspace* ws) { return ws->ev_sorted; }
-float msm_accum_event_offset_ms(MsmWorkspace* ws, hipEvent_t base, int which) {
-  float t = 0.f;
-  hipEvent_t e = which == 0 ? ws->ev0 : which == 1 ? ws->ev1 : ws->trace_ev[which - 2];
-  if (e) (void)hipEventElapsedTime(&t, base, e);
-  return t;
-}
-
-int msm_launch(const MsmInstance& m, MsmWorkspace* ws, const Fr* d_scalars, hipStream_t st) {
-  if (m.curve == 2) return msm_launch_g2(m, ws, d_scalars, st);
-  return msm_launch_t<Fq29Ops>(m, ws, d_scalars, st);
-}
-
-int msm_collect(MsmWorkspace* ws, uint8_t* out_windows, hipStream_t st) {
-  if (ws->launched_n == 0) {
-    memset(out_windows, 0, ws->out_bytes);
-    return G16_OK;
-  }
-  G16_HIP(hipStreamSynchronize(st));
-  (void)hipEventElapsedTime(&ws->last_accum_ms, ws->ev0, ws->ev1);
-  memcpy(out_windows, ws->h_pinned, ws->out_bytes);
+int msm_front_end(const MsmGroup& g, MsmWorkspace* ws, const Fr* d_scalars, hipStream_t st) {
+  const MsmPlan pl = msm_plan_of(g);
+  const uint32_t nrb = g.rows * g.bins, nb = ws->nb;
+  U256 K;
+  msm_make_K(g.c, g.Ws, K);
+  static const bool trace = getenv("G16_TRACE_HOST") != nullptr;
+  auto mark = [&](int k) {
+    if (!trace) return;
+    if (!ws->trace_ev[k]) (void)hipEventCreate(&ws->trace_ev[k]);
+    (void)hipEventRecord(ws->trace_ev[k], st);
+  };
+  const size_t lds = (size_t)nrb * 4;
+  msm_bin_pass_kernel<0><<<g.chunks, kBinThreads, lds, st>>>(d_scalars, g.d_src, pl, K, g.per, g.chunks, ws->d_hist, nullptr,
+                                                             nullptr);
+  mark(0);
+  msm_bin_chunkscan_kernel<<<nrb, 64, 0, st>>>(ws->d_hist, g.chunks, ws->d_bin_cnt);
+  msm_bin_scan_kernel<<<1, 1024, 0, st>>>(ws->d_bin_cnt, nrb, ws->d_bin_start);
+  mark(1);
+  msm_bin_pass_kernel<1><<<g.chunks, kBinThreads, lds, st>>>(d_scalars, g.d_src, pl, K, g.per, g.chunks, ws->d_hist,
+                                                             ws->d_bin_start, ws->d_tmp);
+  mark(2);
+  msm_bin_sort_kernel<<<nrb, 256, 0, st>>>(ws->d_tmp, ws->d_bin_start, pl, ws->d_cnt, ws->d_sorted);
+  const uint32_t ntiles = (nb + kScanTile - 1) / kScanTile;
+  msm_scan_tiles_kernel<<<ntiles, 256, 0, st>>>(ws->d_cnt, nb, g.task_len, ws->d_tile_a, ws->d_tile_b, ws->d_tile_c);
+  msm_scan_top_kernel<<<1, 1024, 0, st>>>(ws->d_tile_a, ws->d_tile_b, ws->d_tile_c, ntiles, ws->d_off + nb, ws->d_toff + nb,
+                                          ws->d_foff + nb);
+  msm_scan_apply_kernel<<<ntiles, 256, 0, st>>>(ws->d_cnt, nb, g.task_len, ws->d_tile_a, ws->d_tile_b, ws->d_tile_c,
+                                                ws->d_off, ws->d_toff, ws->d_foff);
+  mark(3);
+  G16_HIP(hipGetLastError());
+  G16_HIP(hipEventRecord(ws->ev_sorted, st));
   return G16_OK;
 }
 
-int msm_run(const MsmInstance& m, MsmWorkspace* ws, const Fr* d_scalars, uint8_t* out_windows,
-            hipStream_t st) {
-  int rc = msm_launch(m, ws, d_scalars, st);
+int msm_build_queue(const MsmGroup& g, MsmWorkspace* ws, MsmLaneWs& ln, hipStream_t st) {
+  const uint32_t nbk = ln.key_hi - ln.key_lo;
+  G16_HIP(hipMemsetAsync(ln.d_class, 0, 2 * kRemClasses * 4, st));
+  msm_rem_count_kernel<<<(nbk + 255) / 256, 256, 0, st>>>(ws->d_cnt, ln.key_lo, ln.key_hi, g.task_len, ln.d_class);
+  msm_task_fill_kernel<<<(nbk + 255) / 256, 256, 0, st>>>(ws->d_off, ws->d_toff, ws->d_foff, ln.key_lo, ln.key_hi, g.task_len,
+                                                          ln.d_task_desc, ln.d_qdesc, ln.d_class, ln.d_class + kRemClasses);
+  G16_HIP(hipGetLastError());
+  return G16_OK;
+}
+
+int msm_launch(const MsmGroup& g, MsmWorkspace* ws, const Fr* d_scalars, hipStream_t st, hipStream_t st2) {
+  ws->launched = true;
+  ws->empty = (g.n == 0);
+  for (auto& ln : ws->lane) ln.last_accum_ms = 0.f;
+  if (g.n == 0) return G16_OK;
+  {
+    // > 64 KiB of dynamic LDS would need the opt-in; the binning passes stay below 48 KiB by construction.
+    // (The attribute is per device and per kernel; nothing to set here any more.)
+  }
+  int rc = msm_front_end(g, ws, d_scalars, st);
   if (rc) return rc;
-  return msm_collect(ws, out_windows, st);
+  if (ws->lane[1].active) {
+    hipStream_t s2 = st2 ? st2 : st;
+    if (s2 != st) G16_HIP(hipStreamWaitEvent(s2, ws->ev_sorted, 0));
+    // the longer chain first when both share a stream
+    if ((rc = msm_launch_lane_g2(g, ws, ws->lane[1], s2))) return rc;
+  }
+  if (ws->lane[0].active) {
+    if ((rc = msm_launch_lane_t<Fq29Ops>(g, ws, ws->lane[0], g.d_bases, st))) return rc;
+  }
+  return G16_OK;
+}
+
+int msm_collect(const MsmGroup& g, MsmWorkspace* ws, MsmResult* out) {
+  for (auto& p : out->g1) xyzz_set_inf(p);
+  xyzz_set_inf(out->g2);
+  if (!ws->launched || ws->empty) return G16_OK;
+  for (int l = 0; l < 2; l++) {
+    MsmLaneWs& ln = ws->lane[l];
+    if (!ln.active) continue;
+    G16_HIP(hipEventSynchronize(ln.ev_done));
+    (void)hipEventElapsedTime(&ln.last_accum_ms, ln.ev0, ln.ev1);
+    if (l == 0) {
+      const G1XYZZ* rows = reinterpret_cast<const G1XYZZ*>(ln.h_pinned);
+      for (int s = 0; s < g.nsec; s++) msm_combine_windows<FqOps>(out->g1[s], rows + (size_t)s * g.rps, g.W, g.c, g.ones);
+    } else {
+      const G2XYZZ* rows = reinterpret_cast<const G2XYZZ*>(ln.h_pinned);
+      msm_combine_windows<Fq2Ops>(out->g2, rows, g.W, g.c, g.ones);
+    }
+  }
+  return G16_OK;
+}
+
+float msm_last_accum_ms(const MsmWorkspace* ws, int lane) { return ws->lane[lane & 1].last_accum_ms; }
+void msm_set_waves(MsmWorkspace* ws, uint32_t waves_per_simd) { ws->waves_per_simd = waves_per_simd; }
+// which: 0..3 front-end marks (lane ignored), 4/5 accumulate start/end, 6..9 the lane's marks
+float msm_event_offset_ms(MsmWorkspace* ws, hipEvent_t base, int lane, int which) {
+  float t = 0.f;
+  const MsmLaneWs& ln = ws->lane[lane & 1];
+  hipEvent_t e = which < 4 ? ws->trace_ev[which] : which == 4 ? ln.ev0 : which == 5 ? ln.ev1 : ln.trace_ev[(which - 6) & 3];
+  if (e && hipEventQuery(e) == hipSuccess) (void)hipEventElapsedTime(&t, base, e);
+  return t;
 }
 
 }  // namespace g16

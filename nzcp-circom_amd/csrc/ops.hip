@@ -100,29 +100,33 @@ static int multiexp_impl(int device, int curve, const uint8_t* bases, const uint
   int rc = dev_check(device);
   if (rc) return rc;
   if (n >= 0x7fffffffu) { set_error("multiexp: too many points"); return G16_E_ARG; }
-  MsmInstance m;
+  MsmGroup m;
   MsmConfig cfg;
   cfg.c = window_bits;
   MsmWorkspace* ws = nullptr;
   DevBuf ds;
   hipStream_t st = nullptr;
-  XYZZ<F> total;
-  rc = msm_instance_create(m, curve, bases, (uint32_t)n, 0, cfg);
-  if (!rc) rc = msm_workspace_create(&ws, &m, 1);
+  MsmSectionIn sec;
+  if (curve == 2) sec.bases2_host = bases; else sec.bases_host = bases;
+  sec.n_total = (uint32_t)n;
+  rc = msm_group_create(m, &sec, 1, cfg);
+  if (!rc) rc = msm_workspace_create(&ws, m);
   if (!rc) rc = ds.alloc(n * 32);
   if (!rc && hipMemcpy(ds.p, scalars, n * 32, hipMemcpyHostToDevice) != hipSuccess) { set_error("hipMemcpy failed"); rc = G16_E_HIP; }
   if (!rc && hipStreamCreate(&st) != hipSuccess) { set_error("hipStreamCreate failed"); rc = G16_E_HIP; }
-  std::vector<uint8_t> win((size_t)(m.W + 1) * sizeof(XYZZ<F>) + 16);
-  if (!rc) rc = msm_run(m, ws, (const Fr*)ds.p, win.data(), st);
+  MsmResult res;
+  if (!rc) rc = msm_launch(m, ws, (const Fr*)ds.p, st, st);
+  if (!rc) rc = msm_collect(m, ws, &res);
   if (!rc) {
-    msm_combine_windows<F>(total, win.data(), m.W, m.c);
+    XYZZ<F> total;
+    memcpy(&total, curve == 2 ? (const void*)&res.g2 : (const void*)&res.g1[0], sizeof(total));
     Affine<F> r;
     xyzz_to_affine(r, total);
     to_std_bytes<F>(out, r);
   }
   if (st) (void)hipStreamDestroy(st);
   msm_workspace_destroy(ws);
-  msm_instance_destroy(m);
+  msm_group_destroy(m);
   return rc;
 }
 

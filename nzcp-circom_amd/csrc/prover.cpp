@@ -121,19 +121,23 @@ struct g16_prover {
   KeyPoints kp;
   QapCsr csr;
   NttTables ntt;
-  MsmInstance msm[5];  // A, B1, B2, C, H: resident bases, shared by every context
+  // Resident bases, shared by every context.  grp[0] = the witness group: sections A, B1, C share one front end,
+  // B2 (the G2 twin of B1's points) rides on B1's sorted buckets; grp[1] = H; grp[2] = B2 on its own (only for a
+  // malformed key whose sections 6 and 7 disagree on the points at infinity, else empty).
+  MsmGroup grp[3];
+  bool b2_solo = false;
+  bool shard_begun = false;   // between g16_shard_begin and g16_shard_end
   // Per-proof scratch.  Two contexts so that g16_prove_batch can have proof i+1 on the GPU while the
   // host collects and finishes proof i (BASELINE config 3); single proofs use ctx[0].
   struct ProofCtx {
-    hipStream_t st = nullptr;                                         // QAP -> NTT -> H-MSM (critical chain)
-    hipStream_t mst[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};  // A, B1, B2, C on their own streams; [4] = st
-    MsmWorkspace* ws[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};  // one per MSM: all five run concurrently
+    hipStream_t st = nullptr;                        // QAP -> NTT -> H-MSM (critical chain)
+    hipStream_t wst = nullptr, wst2 = nullptr;       // witness group: front end + G1 lane; G2 lane
+    MsmWorkspace* ws[3] = {nullptr, nullptr, nullptr};   // one per group: they run concurrently
     hipEvent_t ev[8] = {};
-    hipEvent_t mev[5][2] = {};
+    hipEvent_t mev[3][2] = {};
     F29 *d_a = nullptr, *d_b = nullptr, *d_c = nullptr;   // QAP/NTT vectors, lazy 9x29 format
     Fr* d_p = nullptr;                                    // H-MSM scalars, standard form
     Fr* d_w = nullptr;                                    // batch mode: this context's witness copy
-    std::vector<uint8_t> winbuf;
     g16_timings tm{};
   };
   static constexpr int kCtx = 2;
@@ -150,7 +154,8 @@ struct g16_prover {
       void* vs[] = {c.d_a, c.d_b, c.d_c, c.d_p, c.d_w};
       for (void* p : vs) if (p) (void)hipFree(p);
       for (auto& w : c.ws) msm_workspace_destroy(w);
-      for (int i = 0; i < 4; i++) if (c.mst[i] && c.mst[i] != c.st) (void)hipStreamDestroy(c.mst[i]);
+      if (c.wst && c.wst != c.st) (void)hipStreamDestroy(c.wst);
+      if (c.wst2 && c.wst2 != c.st) (void)hipStreamDestroy(c.wst2);
       for (auto& e : c.mev) { if (e[0]) (void)hipEventDestroy(e[0]); if (e[1]) (void)hipEventDestroy(e[1]); }
       for (auto& e : c.ev) if (e) (void)hipEventDestroy(e);
       if (c.st) (void)hipStreamDestroy(c.st);
@@ -162,7 +167,7 @@ struct g16_prover {
     }
     if (csr.long_rows) (void)hipFree(csr.long_rows);
     ntt_tables_destroy(ntt);
-    for (auto& m : msm) msm_instance_destroy(m);
+    for (auto& m : grp) msm_group_destroy(m);
   }
 };
 
@@ -308,48 +313,68 @@ static int create_impl(const uint8_t* zkey, size_t len, const g16_opts* opts, g1
   if ((rc = build_csr(P, s4))) return rc;
   if ((rc = ntt_tables_create(P->ntt, P->L, P->st))) return rc;
   MsmConfig cfg;
-  cfg.c = opts ? opts->window_bits : 0;
   cfg.task_len = opts ? opts->task_len : 0;
-  cfg.precomp = opts ? (int)((opts->flags >> 8) & 0xffu) : 0;
-  const uint32_t totals[5] = {P->nVars, P->nVars, P->nVars, nC, P->N};
-  const uint32_t base_off[5] = {0, 0, 0, P->nPublic + 1, 0};
-  const int curve[5] = {1, 1, 2, 1, 1};
-  // tuning override: G16_WINDOW_BITS="a,b1,b2,c,h" (0 = auto), G16_TASK_LEN=n
-  int c_over[5] = {0, 0, 0, 0, 0};
-  if (const char* e = getenv("G16_WINDOW_BITS")) sscanf(e, "%d,%d,%d,%d,%d", &c_over[0], &c_over[1], &c_over[2], &c_over[3], &c_over[4]);
+  // tuning overrides: G16_WINDOW_BITS="witness,h" (0 = auto), G16_TASK_LEN=n
+  int c_over[2] = {0, 0};
+  if (const char* e = getenv("G16_WINDOW_BITS")) sscanf(e, "%d,%d", &c_over[0], &c_over[1]);
   if (const char* e = getenv("G16_TASK_LEN")) cfg.task_len = atoi(e);
-  for (int i = 0; i < 5; i++) {
-    uint32_t lo, hi;
-    cfg.c = c_over[i] ? c_over[i] : (opts ? opts->window_bits : 0);
-    cfg.dense = (i == 4);   // H scalars are uniform in Fr; witness scalars are mostly 0/1/small
-    shard_range(totals[i], P->shard_rank, P->shard_count, lo, hi);
-    const size_t psz = curve[i] == 2 ? 128 : 64;
-    if ((rc = msm_instance_create(P->msm[i], curve[i], sb[i].p + (size_t)lo * psz, hi - lo, base_off[i] + lo, cfg)))
+  {
+    // witness group: A over w, B1 (+ its G2 twin B2) over w, C over w[p+1:]; each section's point range sharded
+    uint32_t lo[3], hi[3];
+    shard_range(P->nVars, P->shard_rank, P->shard_count, lo[0], hi[0]);
+    lo[1] = lo[0]; hi[1] = hi[0];
+    shard_range(nC, P->shard_rank, P->shard_count, lo[2], hi[2]);
+    MsmSectionIn secs[3];
+    secs[0].bases_host = sb[0].p + (size_t)lo[0] * 64; secs[0].n_total = hi[0] - lo[0]; secs[0].scalar_offset = lo[0];
+    secs[1].bases_host = sb[1].p + (size_t)lo[1] * 64; secs[1].bases2_host = sb[2].p + (size_t)lo[1] * 128;
+    secs[1].n_total = hi[1] - lo[1]; secs[1].scalar_offset = lo[1];
+    secs[2].bases_host = sb[3].p + (size_t)lo[2] * 64; secs[2].n_total = hi[2] - lo[2];
+    secs[2].scalar_offset = P->nPublic + 1 + lo[2];
+    cfg.c = c_over[0] ? c_over[0] : (opts ? opts->window_bits : 0);
+    cfg.dense = false;    // witness scalars are mostly 0/1/small
+    cfg.precomp = 1;
+    rc = msm_group_create(P->grp[0], secs, 3, cfg);
+    if (rc == G16_E_FORMAT) {   // sections 6 / 7 disagree on infinity: B2 gets its own front end
+      msm_group_destroy(P->grp[0]);
+      MsmSectionIn b2 = secs[1];
+      b2.bases_host = nullptr;
+      secs[1].bases2_host = nullptr;
+      if ((rc = msm_group_create(P->grp[0], secs, 3, cfg))) return rc;
+      if ((rc = msm_group_create(P->grp[2], &b2, 1, cfg))) return rc;
+      P->b2_solo = true;
+    } else if (rc) {
       return rc;
+    }
+    // H over the quotient evaluations: dense (uniform in Fr)
+    MsmSectionIn hsec;
+    uint32_t hlo, hhi;
+    shard_range(P->N, P->shard_rank, P->shard_count, hlo, hhi);
+    hsec.bases_host = sb[4].p + (size_t)hlo * 64; hsec.n_total = hhi - hlo; hsec.scalar_offset = hlo;
+    cfg.c = c_over[1] ? c_over[1] : (opts ? opts->window_bits : 0);
+    cfg.dense = true;
+    cfg.precomp = opts ? (int)((opts->flags >> 8) & 0xffu) : 0;
+    if ((rc = msm_group_create(P->grp[1], &hsec, 1, cfg))) return rc;
   }
   // G16_SERIAL_MSM=1 (profiling aid): every MSM on the main stream, so kernel times are standalone
   const bool serial = getenv("G16_SERIAL_MSM") && atoi(getenv("G16_SERIAL_MSM"));
-  size_t wb = 0;
-  for (auto& m : P->msm) {
-    const size_t b = (size_t)(m.W + 1) * msm_point_bytes(m.curve);
-    if (b > wb) wb = b;
-  }
   for (auto& c : P->ctx) {
-    for (int i = 0; i < 5; i++) {
-      if ((rc = msm_workspace_create(&c.ws[i], &P->msm[i], 1))) return rc;
-      // the G2 chain (B2) is the longest after the H chain: high priority as well
-      if (i < 4 && serial) c.mst[i] = c.st;
-      else if (i < 4) G16_HIP(hipStreamCreateWithPriority(&c.mst[i], hipStreamNonBlocking, i == 2 ? prio_hi : prio_lo));
-      else c.mst[4] = c.st;
+    for (int i = 0; i < 3; i++) {
+      if ((rc = msm_workspace_create(&c.ws[i], P->grp[i]))) return rc;
       G16_HIP(hipEventCreate(&c.mev[i][0]));
       G16_HIP(hipEventCreate(&c.mev[i][1]));
+    }
+    if (serial) {
+      c.wst = c.wst2 = c.st;
+    } else {
+      // the G2 lane (B2) is the longest chain after the H chain: high priority as well
+      G16_HIP(hipStreamCreateWithPriority(&c.wst, hipStreamNonBlocking, prio_lo));
+      G16_HIP(hipStreamCreateWithPriority(&c.wst2, hipStreamNonBlocking, prio_hi));
     }
     const size_t vb = (size_t)P->N * sizeof(F29);
     G16_HIP(hipMalloc(&c.d_a, vb));
     G16_HIP(hipMalloc(&c.d_b, vb));
     G16_HIP(hipMalloc(&c.d_c, vb));
     G16_HIP(hipMalloc(&c.d_p, (size_t)P->N * sizeof(Fr)));
-    c.winbuf.resize(wb);
   }
   G16_HIP(hipStreamSynchronize(P->st));
   return G16_OK;
@@ -507,110 +532,139 @@ static int finish_impl(const KeyPoints* P, const Partial* parts, uint32_t count,
 
 using ProofCtx = g16_prover::ProofCtx;
 
-template <class F>
-static int collect_one_msm(g16_prover* P, ProofCtx& c, int i, XYZZ<F>& out) {
-  int rc = msm_collect(c.ws[i], c.winbuf.data(), c.mst[i]);
-  if (rc) return rc;
-  (void)hipEventElapsedTime(&c.tm.msm_ms[i], c.mev[i][0], c.mev[i][1]);
-  c.tm.msm_accum_kernel_ms[i] = msm_last_accum_ms(c.ws[i]);
-  msm_combine_windows<F>(out, c.winbuf.data(), P->msm[i].W, P->msm[i].c);
+// The device pipeline of one proof on context `c`, in pieces that only enqueue (no host synchronisation).  The
+// witness group (A, B1, B2, C) does not depend on the H polynomial: it runs on its own streams and overlaps with
+// QAP -> NTTs -> join -> H-MSM on the context's main stream.
+static void trace_host(const char* what, const std::chrono::steady_clock::time_point& t0) {
+  static const bool on = getenv("G16_TRACE_HOST") != nullptr;
+  if (on)
+    fprintf(stderr, "[g16 host] %s enqueued at %.3f ms\n", what,
+            std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
+}
+// experiment knob: G16_ACC_WAVES = "wh" digits: wavefronts per SIMD of the persistent accumulate grids (0 = full)
+static uint32_t acc_waves(int which) {
+  static const char* occ_s = getenv("G16_ACC_WAVES");
+  return (occ_s && strlen(occ_s) == 2) ? (uint32_t)(occ_s[which] - '0') : 0u;
+}
+// witness group (+ the solo B2 group of a malformed key) on its own streams, after c.ev[2]
+static int launch_witness(g16_prover* P, ProofCtx& c, const Fr* d_w) {
+  int rc;
+  if (c.wst != c.st) G16_HIP(hipStreamWaitEvent(c.wst, c.ev[2], 0));
+  for (int gi : {0, 2}) {
+    if (gi == 2 && !P->b2_solo) continue;
+    msm_set_waves(c.ws[gi], acc_waves(0));
+    hipStream_t s1 = gi == 0 ? c.wst : c.wst2;
+    if (gi == 2 && c.wst2 != c.st) G16_HIP(hipStreamWaitEvent(c.wst2, c.ev[2], 0));
+    G16_HIP(hipEventRecord(c.mev[gi][0], s1));
+    if ((rc = msm_launch(P->grp[gi], c.ws[gi], d_w, s1, gi == 0 ? c.wst2 : s1))) return rc;
+    G16_HIP(hipEventRecord(c.mev[gi][1], s1));
+  }
   return G16_OK;
 }
-
-// Enqueue the device pipeline of one proof on context `c` (no host synchronisation).  The four
-// witness MSMs (A, B1, B2, C) do not depend on the H polynomial: they run on their own streams and
-// overlap with QAP -> NTTs -> join -> H-MSM on the context's main stream.
+// QAP evaluation, then the odd-coset evaluation (iNTT, coset shift, NTT) of the vectors in `mask` (bit 0 = A,
+// 1 = B, 2 = C) on the main stream
+static int launch_qap_ntt(g16_prover* P, ProofCtx& c, const Fr* d_w, uint32_t mask) {
+  int rc;
+  if ((rc = qap_eval(P->csr, d_w, c.d_a, c.d_b, c.d_c, c.st))) return rc;
+  G16_HIP(hipEventRecord(c.ev[3], c.st));
+  F29* all[3] = {c.d_a, c.d_b, c.d_c};
+  F29* vecs[3];
+  int nv = 0;
+  for (int v = 0; v < 3; v++)
+    if (mask & (1u << v)) vecs[nv++] = all[v];
+  if (nv) {
+    if ((rc = ntt_dif_inverse_coset(P->ntt, vecs, nv, c.st))) return rc;   // iNTT + (1/N, w_2N^i) table
+    if ((rc = ntt_dit_forward(P->ntt, vecs, nv, c.st))) return rc;
+  }
+  return G16_OK;
+}
+// P = A'.B' - C' over [lo, hi) of the domain, then the H-MSM of this handle's point range
+static int launch_join_h(g16_prover* P, ProofCtx& c, uint32_t lo, uint32_t hi) {
+  int rc;
+  if (hi > lo && (rc = ntt_join_abc(c.d_a + lo, c.d_b + lo, c.d_c + lo, c.d_p + lo, hi - lo, c.st))) return rc;
+  G16_HIP(hipEventRecord(c.ev[4], c.st));
+  msm_set_waves(c.ws[1], acc_waves(1));
+  G16_HIP(hipEventRecord(c.mev[1][0], c.st));
+  if ((rc = msm_launch(P->grp[1], c.ws[1], c.d_p, c.st, c.st))) return rc;
+  G16_HIP(hipEventRecord(c.mev[1][1], c.st));
+  return G16_OK;
+}
 static int launch_ctx(g16_prover* P, ProofCtx& c, const Fr* d_w) {
   G16_HIP(hipSetDevice(P->device));
   int rc;
-  static const bool trace_host = getenv("G16_TRACE_HOST") != nullptr;
   const auto th0 = std::chrono::steady_clock::now();
-  auto th = [&](const char* what) {
-    if (trace_host)
-      fprintf(stderr, "[g16 host] %s enqueued at %.3f ms\n", what,
-              std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - th0).count());
-  };
   G16_HIP(hipEventRecord(c.ev[2], c.st));
-  // critical chain first (host launch order matters: ~60 witness-MSM launches cost ~0.3 ms of host time)
-  if ((rc = qap_eval(P->csr, d_w, c.d_a, c.d_b, c.d_c, c.st))) return rc;
-  G16_HIP(hipEventRecord(c.ev[3], c.st));
-  F29* vecs[3] = {c.d_a, c.d_b, c.d_c};
-  if ((rc = ntt_dif_inverse_coset(P->ntt, vecs, 3, c.st))) return rc;   // iNTT + (1/N, w_2N^i) table
-  if ((rc = ntt_dit_forward(P->ntt, vecs, 3, c.st))) return rc;
-  if ((rc = ntt_join_abc(c.d_a, c.d_b, c.d_c, c.d_p, P->N, c.st))) return rc;
-  G16_HIP(hipEventRecord(c.ev[4], c.st));
-  th("qap+ntt");
-  static const int order[4] = {2, 3, 0, 1};   // longest chains first: B2 (G2), C, A, B1
-  // experiment knobs: G16_GATE = 5 digits (A,B1,B2,C,H): 1 = that MSM's accumulate waits for the NTT chain,
-  // 2 = for the H-MSM's sort (the H-MSM is then enqueued first), 3 = the WHOLE MSM starts after the H-MSM's sort;
-  // G16_ACC_WAVES = 5 digits: wavefronts per SIMD of the persistent accumulate grid (0 = full)
-  static const char* gate_s = getenv("G16_GATE");
-  static const char* occ_s = getenv("G16_ACC_WAVES");
-  static const bool chain = getenv("G16_CHAIN") != nullptr;
-  bool h_first = false;
-  for (int i = 0; i < 4; i++) h_first |= gate_s && strlen(gate_s) == 5 && (gate_s[i] == '2' || gate_s[i] == '3');
-  auto launch_h = [&]() -> int {
-    msm_set_schedule(c.ws[4], nullptr, (occ_s && strlen(occ_s) == 5) ? (uint32_t)(occ_s[4] - '0') : 0);
-    G16_HIP(hipEventRecord(c.mev[4][0], c.st));
-    int r = msm_launch(P->msm[4], c.ws[4], c.d_p, c.st);
-    if (r) return r;
-    G16_HIP(hipEventRecord(c.mev[4][1], c.st));
-    return G16_OK;
-  };
-  if (h_first && (rc = launch_h())) return rc;
-  for (int oi = 0; oi < 4; oi++) {
-    const int i = order[oi];
-    const char g = (gate_s && strlen(gate_s) == 5) ? gate_s[i] : '0';
-    const uint32_t occ = (occ_s && strlen(occ_s) == 5) ? (uint32_t)(occ_s[i] - '0') : 0;
-    hipEvent_t gate = g == '1' ? c.ev[4] : g == '2' ? msm_sorted_event(c.ws[4]) : nullptr;
-    if (chain && oi > 0) gate = msm_accum_done_event(c.ws[order[oi - 1]]);   // one witness accumulate at a time
-    msm_set_schedule(c.ws[i], gate, occ);
-    if (c.mst[i] != c.st) G16_HIP(hipStreamWaitEvent(c.mst[i], c.ev[2], 0));
-    if (g == '3' && c.mst[i] != c.st) G16_HIP(hipStreamWaitEvent(c.mst[i], msm_sorted_event(c.ws[4]), 0));   // whole MSM after the H sort
-    G16_HIP(hipEventRecord(c.mev[i][0], c.mst[i]));
-    if ((rc = msm_launch(P->msm[i], c.ws[i], d_w, c.mst[i]))) return rc;
-    G16_HIP(hipEventRecord(c.mev[i][1], c.mst[i]));
-    th("witness msm");
-  }
-  if (!h_first && (rc = launch_h())) return rc;
-  th("h msm");
+  // critical chain first (host launch order matters: the witness group's ~35 launches cost host time)
+  if ((rc = launch_qap_ntt(P, c, d_w, 7u))) return rc;
+  trace_host("qap+ntt", th0);
+  if ((rc = launch_witness(P, c, d_w))) return rc;
+  trace_host("witness msm", th0);
+  // a sharded handle joins only the slice of the domain its H bases cover
+  uint32_t lo, hi;
+  shard_range(P->N, P->shard_rank, P->shard_count, lo, hi);
+  if ((rc = launch_join_h(P, c, lo, hi))) return rc;
+  trace_host("h msm", th0);
   return G16_OK;
 }
 
-// Wait for context `c` and fold each MSM's window sums, in two halves: the witness MSMs (A, B1, B2, C
-// finish long before the H-MSM), then H.  The caller does the H-independent part of the proof
-// assembly between the two.
+// Wait for context `c` and fold each MSM's row sums, in two halves: the witness group (A, B1, B2, C finish
+// long before the H-MSM), then H.  The caller does the H-independent part of the proof assembly between the two.
 static int collect_witness_msms(g16_prover* P, ProofCtx& c, Partial& out) {
-  int rc;
-  if ((rc = collect_one_msm<FqOps>(P, c, 0, out.A))) return rc;
-  if ((rc = collect_one_msm<FqOps>(P, c, 1, out.B1))) return rc;
-  if ((rc = collect_one_msm<Fq2Ops>(P, c, 2, out.B2))) return rc;
-  if ((rc = collect_one_msm<FqOps>(P, c, 3, out.C))) return rc;
+  MsmResult r;
+  int rc = msm_collect(P->grp[0], c.ws[0], &r);
+  if (rc) return rc;
+  out.A = r.g1[0];
+  out.B1 = r.g1[1];
+  out.C = r.g1[2];
+  out.B2 = r.g2;
+  c.tm.msm_accum_kernel_ms[0] = msm_last_accum_ms(c.ws[0], 0);
+  c.tm.msm_accum_kernel_ms[1] = c.tm.msm_accum_kernel_ms[3] = 0.f;
+  c.tm.msm_accum_kernel_ms[2] = msm_last_accum_ms(c.ws[0], 1);
+  if (P->b2_solo) {
+    if ((rc = msm_collect(P->grp[2], c.ws[2], &r))) return rc;
+    out.B2 = r.g2;
+    c.tm.msm_accum_kernel_ms[2] = msm_last_accum_ms(c.ws[2], 1);
+  }
   return G16_OK;
 }
 static int collect_h_msm(g16_prover* P, ProofCtx& c, Partial& out) {
-  int rc;
-  if ((rc = collect_one_msm<FqOps>(P, c, 4, out.H))) return rc;
+  MsmResult r;
+  int rc = msm_collect(P->grp[1], c.ws[1], &r);
+  if (rc) return rc;
+  out.H = r.g1[0];
+  c.tm.msm_accum_kernel_ms[4] = msm_last_accum_ms(c.ws[1], 0);
   G16_HIP(hipEventRecord(c.ev[5], c.st));
   G16_HIP(hipEventSynchronize(c.ev[5]));
+  if (c.wst != c.st) G16_HIP(hipStreamSynchronize(c.wst));
+  if (c.wst2 != c.st) G16_HIP(hipStreamSynchronize(c.wst2));
   (void)hipEventElapsedTime(&c.tm.qap_ms, c.ev[2], c.ev[3]);
   (void)hipEventElapsedTime(&c.tm.ntt_ms, c.ev[3], c.ev[4]);
   (void)hipEventElapsedTime(&c.tm.total_ms, c.ev[2], c.ev[5]);
+  // msm_ms: [0] = witness group on its main stream (front end + G1 lane over A, B1, C), [2] = until the G2 lane
+  // (B2) is done, [4] = H group; [1], [3] unused since the witness MSMs share one front end
+  float wg = 0.f, hg = 0.f, g2 = 0.f;
+  (void)hipEventElapsedTime(&wg, c.mev[0][0], c.mev[0][1]);
+  (void)hipEventElapsedTime(&hg, c.mev[1][0], c.mev[1][1]);
+  g2 = msm_event_offset_ms(c.ws[P->b2_solo ? 2 : 0], c.mev[P->b2_solo ? 2 : 0][0], 1, 9);
+  c.tm.msm_ms[0] = wg; c.tm.msm_ms[1] = 0.f; c.tm.msm_ms[2] = g2; c.tm.msm_ms[3] = 0.f; c.tm.msm_ms[4] = hg;
   static const bool trace_dev = getenv("G16_TRACE_HOST") != nullptr;
   if (trace_dev) {
-    static const char* nm[5] = {"A", "B1", "B2", "C", "H"};
     float t_ntt0 = 0, t_ntt1 = 0;
     (void)hipEventElapsedTime(&t_ntt0, c.ev[2], c.ev[3]);
     (void)hipEventElapsedTime(&t_ntt1, c.ev[2], c.ev[4]);
     fprintf(stderr, "[g16 dev] qap 0..%.3f  ntt+join ..%.3f  total %.3f\n", t_ntt0, t_ntt1, c.tm.total_ms);
-    for (int i = 0; i < 5; i++) {
+    static const char* nm[2] = {"W", "H"};
+    for (int gi = 0; gi < 2; gi++) {
       float s0 = 0, s1 = 0;
-      (void)hipEventElapsedTime(&s0, c.ev[2], c.mev[i][0]);
-      (void)hipEventElapsedTime(&s1, c.ev[2], c.mev[i][1]);
-      auto off = [&](int k) { return msm_accum_event_offset_ms(c.ws[i], c.ev[2], k); };
-      fprintf(stderr, "[g16 dev] %-2s start %.3f digits %.3f sort0 %.3f scan %.3f sort1 %.3f | accumulate %.3f..%.3f | "
-              "combine %.3f reduce %.3f tree.. end %.3f\n", nm[i], s0, off(2), off(3), off(4), off(5), off(0), off(1),
-              off(7), off(8), s1);
+      (void)hipEventElapsedTime(&s0, c.ev[2], c.mev[gi][0]);
+      (void)hipEventElapsedTime(&s1, c.ev[2], c.mev[gi][1]);
+      auto off = [&](int lane, int k) { return msm_event_offset_ms(c.ws[gi], c.ev[2], lane, k); };
+      fprintf(stderr, "[g16 dev] %s  start %.3f pass0 %.3f binscan %.3f pass1 %.3f binsort+scans %.3f | G1 queue %.3f accumulate "
+              "%.3f..%.3f combine %.3f reduce %.3f end %.3f (stream end %.3f)\n", nm[gi], s0, off(0, 0), off(0, 1), off(0, 2),
+              off(0, 3), off(0, 6), off(0, 4), off(0, 5), off(0, 7), off(0, 8), off(0, 9), s1);
+      if (gi == 0)
+        fprintf(stderr, "[g16 dev] W2 (G2 lane) queue %.3f accumulate %.3f..%.3f combine %.3f reduce %.3f end %.3f\n",
+                off(1, 6), off(1, 4), off(1, 5), off(1, 7), off(1, 8), off(1, 9));
     }
   }
   const float up = P->tm.upload_ms;
@@ -673,6 +727,61 @@ int g16_prove_partial(g16_prover* p, uint32_t slot, uint8_t partial[G16_PARTIAL_
   Partial part;
   int rc = device_impl(p, slot, part);
   if (rc) return rc;
+  memcpy(partial, &part, sizeof(part));
+  return G16_OK;
+}
+
+// Sharded H pipeline (BASELINE config 4): see include/g16_prover.h.
+int g16_shard_begin(g16_prover* p, uint32_t slot, uint32_t vec_mask, void* const out_vecs[3]) {
+  if (!p || (vec_mask & ~7u)) { set_error("g16_shard_begin: bad argument"); return G16_E_ARG; }
+  std::lock_guard<std::mutex> lk(p->mu);
+  if (slot >= p->slot_dev.size() || !p->slot_dev[slot]) { set_error("witness slot not staged"); return G16_E_STATE; }
+  for (int v = 0; v < 3; v++)
+    if ((vec_mask & (1u << v)) && (!out_vecs || !out_vecs[v])) { set_error("g16_shard_begin: missing output vector"); return G16_E_ARG; }
+  G16_HIP(hipSetDevice(p->device));
+  ProofCtx& c = p->ctx[0];
+  int rc;
+  G16_HIP(hipEventRecord(c.ev[2], c.st));
+  if (vec_mask) {
+    if ((rc = launch_qap_ntt(p, c, p->slot_dev[slot], vec_mask))) return rc;
+  } else {
+    G16_HIP(hipEventRecord(c.ev[3], c.st));
+  }
+  if ((rc = launch_witness(p, c, p->slot_dev[slot]))) return rc;   // keeps running behind the exchange
+  const F29* src[3] = {c.d_a, c.d_b, c.d_c};
+  for (int v = 0; v < 3; v++)
+    if (vec_mask & (1u << v))
+      G16_HIP(hipMemcpyAsync(out_vecs[v], src[v], (size_t)p->N * sizeof(F29), hipMemcpyDefault, c.st));
+  G16_HIP(hipStreamSynchronize(c.st));
+  p->shard_begun = true;
+  return G16_OK;
+}
+
+int g16_shard_end(g16_prover* p, uint32_t slot, const void* const slices[3], uint8_t partial[G16_PARTIAL_BYTES]) {
+  if (!p || !slices || !partial) { set_error("NULL argument"); return G16_E_ARG; }
+  std::lock_guard<std::mutex> lk(p->mu);
+  if (!p->shard_begun) { set_error("g16_shard_end without g16_shard_begin"); return G16_E_STATE; }
+  p->shard_begun = false;
+  G16_HIP(hipSetDevice(p->device));
+  ProofCtx& c = p->ctx[0];
+  uint32_t lo, hi;
+  shard_range(p->N, p->shard_rank, p->shard_count, lo, hi);
+  F29* dst[3] = {c.d_a, c.d_b, c.d_c};
+  int rc = G16_OK;
+  for (int v = 0; v < 3 && !rc; v++) {
+    if (hi > lo && !slices[v]) { set_error("g16_shard_end: missing slice"); rc = G16_E_ARG; break; }
+    if (hi > lo && hipMemcpyAsync(dst[v] + lo, slices[v], (size_t)(hi - lo) * sizeof(F29), hipMemcpyDefault, c.st) != hipSuccess) {
+      set_error("g16_shard_end: copy of a slice failed");
+      rc = G16_E_HIP;
+    }
+  }
+  if (!rc) rc = launch_join_h(p, c, lo, hi);
+  Partial part;
+  if (rc) {   // drain the witness group that g16_shard_begin started, then report
+    (void)collect_witness_msms(p, c, part);
+    return rc;
+  }
+  if ((rc = collect_ctx(p, c, part))) return rc;
   memcpy(partial, &part, sizeof(part));
   return G16_OK;
 }
@@ -795,8 +904,12 @@ void g16_shard_range(uint32_t total, int32_t rank, int32_t count, uint32_t* lo, 
 int g16_get_info(const g16_prover* p, g16_info* o) {
   if (!p || !o) { set_error("NULL argument"); return G16_E_ARG; }
   o->n_vars = p->nVars; o->n_public = p->nPublic; o->domain_size = p->N; o->n_coefs = p->nCoefs;
-  o->n_a = p->msm[0].n; o->n_b1 = p->msm[1].n; o->n_b2 = p->msm[2].n; o->n_c = p->msm[3].n; o->n_h = p->msm[4].n;
-  for (int i = 0; i < 5; i++) o->window_bits[i] = (uint32_t)p->msm[i].c;
+  const MsmGroup& w = p->grp[0];
+  o->n_a = w.sec_n[0]; o->n_b1 = w.sec_n[1]; o->n_c = w.sec_n[2]; o->n_h = p->grp[1].n;
+  o->n_b2 = p->b2_solo ? p->grp[2].n : w.sec_n[1];
+  const uint32_t wc = (uint32_t)w.c, b2c = p->b2_solo ? (uint32_t)p->grp[2].c : wc;
+  const uint32_t cs[5] = {wc, wc, b2c, wc, (uint32_t)p->grp[1].c};
+  for (int i = 0; i < 5; i++) o->window_bits[i] = cs[i];
   return G16_OK;
 }
 

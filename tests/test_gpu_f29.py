@@ -167,12 +167,16 @@ def test_x29_madd_fast_and_complete(amd, curve):
     # exceptional pairs at the end: doubling, cancellation
     Ps += [Ps[0], Ps[1], Ps[2], Ps[3]]
     Qs += [Ps[0], grp.neg(Ps[1]), Ps[2], grp.neg(Ps[3])]
-    acc = [_xyzz_of(curve, P, rng) for P in Ps]
+    # G1's hot-loop formula folds -Y1 into a fused product and needs Y1 <= 2p (an affine coordinate or an earlier
+    # fused Y3 < 1.3p: ec29.cuh x29_madd_fast); G2 subtracts with K = 4
+    acc = [_xyzz_of(curve, P, rng, ky=1 if curve == 1 else 2) for P in Ps]
     q = [_affine_m(curve, Q, rng) for Q in Qs]
     out, flags = amd.x29_op(curve, 0, acc, q)           # the hot-loop formula
     for i in range(n):
         assert _decode(curve, out[i]) == grp.add(Ps[i], Qs[i]), i
         _check_bounds(curve, out[i])
+        if curve == 1:
+            assert out[i][1] < 13 * b.Q // 10         # the fused Y3 bound the next iteration relies on
     assert sum(flags[:n]) <= 1                            # the low-limb filter fires on ~2^-26 of ordinary additions
     assert flags[n:] == [1, 1, 1, 1]                      # doubling / cancellation MUST be sent to the redo pass
     out, _ = amd.x29_op(curve, 1, acc, q)                # complete mixed addition (msm_redo_kernel)

@@ -93,6 +93,39 @@ def test_sharded_partials_equal_single(amd):
     last.close()
 
 
+@pytest.mark.parametrize("shards", [2, 3, 5])
+def test_sharded_h_pipeline_equals_single(amd, shards):
+    """BASELINE config 4 without the replicated NTT chain (g16_shard_begin / g16_shard_end): shard v mod G
+    evaluates vector v of (A, B, C) on the coset, every shard receives its slice of all three, joins and
+    multi-exponentiates only its own range.  Same proof bytes as one unsharded handle.  Exchange buffers are host
+    memory here (between processes: an RCCL scatter; inside one process: peer copies)."""
+    import ctypes as C
+    zk, wt, meta = _golden("nzcp513")
+    r, s = f.le(int(meta["r"])), f.le(int(meta["s"]))
+    pvs = [amd.Prover(zk, shard_rank=k, shard_count=shards) for k in range(shards)]
+    n_dom = pvs[0].info.domain_size
+    eb = amd.LAZY_FR_BYTES
+    vecs = [C.create_string_buffer(n_dom * eb) for _ in range(3)]
+    for k, pv in enumerate(pvs):
+        pv.stage(0, wt)
+        mask = sum(1 << v for v in range(3) if v % shards == k)
+        pv.shard_begin(0, mask, [C.addressof(vecs[v]) if (mask >> v) & 1 else 0 for v in range(3)])
+    parts = []
+    for k, pv in enumerate(pvs):
+        lo, hi = amd.shard_range(n_dom, k, shards)
+        sl = [C.create_string_buffer(vecs[v].raw[lo * eb:hi * eb], max(1, (hi - lo) * eb)) for v in range(3)]
+        parts.append(pv.shard_end(0, [C.addressof(x) for x in sl]))
+    proof, pub = pvs[-1].prove_finish(0, parts, r, s)
+    assert proof == meta["proof"] and pub == meta["public"]
+    # protocol errors are reported, not silently mis-proved
+    with pytest.raises(amd.G16Error):
+        pvs[0].shard_end(0, [0, 0, 0])                      # no begin
+    with pytest.raises(amd.G16Error):
+        pvs[0].prove_finish(0, parts[:-1], r, s)            # a missing partial
+    for pv in pvs:
+        pv.close()
+
+
 def test_batch_api(amd):
     import ctypes as C
     zk, wt, meta = _golden("tiny")
