@@ -148,7 +148,7 @@ def batch_leg(amd, args, zkey, wtns, prover0, r, s, log):
     per-proof scratch contexts (proof i+1 on the GPU while the host collects and finishes proof i).
     The witnesses come from host memory, so this figure INCLUDES the PCIe upload of every witness.
     Reported next to the single-proof `value`, never instead of it."""
-    nslots = 4
+    nslots = min(8, max(1, args.batch_proofs))
     wts = [wtns] + [amd.synth_witness(args.n_vars, args.n_public, args.n_constraints, SEED, SEED + 100 + i)
                     for i in range(1, nslots)]
     total = args.batch_proofs
@@ -197,7 +197,9 @@ def main():
     ap.add_argument("--batch-streams", type=int, default=2,
                     help="extra measurement at N=1: throughput mode of BASELINE config 3 (g16_prove_batch over "
                          "independent witnesses); 0 = skip")
-    ap.add_argument("--batch-proofs", type=int, default=32)
+    ap.add_argument("--batch-proofs", type=int, default=1024,
+                    help="proofs in the throughput leg: BASELINE config 3 is stated on 1 024 independent witnesses "
+                         "(8 distinct ones cycled; every proof is compared with its one-by-one result)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -265,15 +267,36 @@ def main():
     gather_out = torch.zeros(amd.PARTIAL_BYTES * world, dtype=torch.uint8, device=xdev)
     lib = amd.load()
     pbuf = ctypes.create_string_buffer(amd.PARTIAL_BYTES)
+    # Sharded H pipeline (g16_shard_begin / g16_shard_end): rank v mod N evaluates vector v of (A, B, C) on the
+    # coset, a scatter per vector hands every rank its slice [lo, hi) of the domain (RCCL over xGMI; equal-size
+    # chunks, padded), each rank joins and multi-exponentiates only its own range of P.
+    EB = amd.LAZY_FR_BYTES
+    N_dom = info.domain_size
+    pad = max(amd.shard_range(N_dom, k, world)[1] - amd.shard_range(N_dom, k, world)[0] for k in range(world)) if sharded else 0
+    my_mask = sum(1 << v for v in range(3) if amd.shard_vector_owner(v, world) == rank) if sharded else 0
+    vec_t = [torch.zeros((N_dom + pad) * EB, dtype=torch.uint8, device=xdev) if (my_mask >> v) & 1 else None
+             for v in range(3)] if sharded else []
+    slice_t = [torch.zeros(max(1, pad) * EB, dtype=torch.uint8, device=xdev) for _ in range(3)] if sharded else []
 
     def step():
         if not sharded:
             rc = prover.prove_staged_raw(0, r, s, pr, pub)
             assert rc == 0, lib.g16_last_error()
             return
-        rc = lib.g16_prove_partial(prover._h, 0, pbuf)
-        assert rc == 0, lib.g16_last_error()
-        gather_in.copy_(torch.frombuffer(pbuf, dtype=torch.uint8))
+        prover.shard_begin(0, my_mask, [vec_t[v].data_ptr() if vec_t[v] is not None else 0 for v in range(3)])
+        for v in range(3):
+            owner = amd.shard_vector_owner(v, world)
+            chunks = None
+            if rank == owner:
+                chunks = []
+                for k in range(world):
+                    lo_k = amd.shard_range(N_dom, k, world)[0]
+                    chunks.append(vec_t[v][lo_k * EB:(lo_k + max(1, pad)) * EB])
+            dist.scatter(slice_t[v], chunks, src=owner)
+        if xdev == "cuda":
+            torch.cuda.synchronize()
+        blob_mine = prover.shard_end(0, [t.data_ptr() for t in slice_t])
+        gather_in.copy_(torch.frombuffer(bytearray(blob_mine), dtype=torch.uint8))
         dist.all_gather_into_tensor(gather_out, gather_in)      # RCCL over xGMI: 768 B per rank
         blob = gather_out.cpu().numpy().tobytes()
         rc = lib.g16_prove_finish(prover._h, 0, blob, world, r, s, ctypes.byref(pr), pub)
@@ -314,6 +337,11 @@ def main():
         rp = amd.Prover(zkey_r, device=dev, window_bits=args.window_bits, task_len=args.task_len)
         zkey_r = None
         rp.stage(0, wtns)
+        sharded_bytes = bytes(pr.a) + bytes(pr.b) + bytes(pr.c)   # the proof the sharded steps assembled
+        pr_u = amd.Proof()
+        assert rp.prove_staged_raw(0, r, s, pr_u, pub) == 0
+        assert bytes(pr_u.a) + bytes(pr_u.b) + bytes(pr_u.c) == sharded_bytes, \
+            "sharded proof differs from the unsharded proof of the same (witness, r, s)"
         for _ in range(args.warmup):
             assert rp.prove_staged_raw(0, r, s, pr, pub) == 0
         fence()
@@ -325,7 +353,8 @@ def main():
         tr = torch.tensor([dtr], dtype=torch.float64, device=xdev)
         dist.all_reduce(tr, op=dist.ReduceOp.MAX)
         replicas = {"proofs_per_sec": round(world * args.steps / float(tr.item()), 3), "scaling": "weak",
-                    "mode": f"{world} independent unsharded provers, one per GPU, no collective"}
+                    "mode": f"{world} independent unsharded provers, one per GPU, no collective",
+                    "sharded_proof_equals_unsharded": True}
         rp.close()
     batch = None
     if world == 1 and args.batch_streams > 0:
@@ -367,7 +396,8 @@ def main():
                                     f"nzcp_live-shaped single proof: nVars={nn}, nConstraints={args.n_constraints}, "
                                     f"nPublic={info.n_public}, domain=2^{N.bit_length() - 1}, nCoefs={k}"),
                        "parallelism": ("1gpu" if world == 1 else
-                                       (f"msm-point-range-shard{world}+allgather" if sharded else f"replicas{world}")),
+                                       (f"msm-point-range-shard{world}+abc-vector-split+scatter+allgather" if sharded
+                                        else f"replicas{world}")),
                        "window_bits": list(info.window_bits)},
             "phases_ms": {"qap": round(acc["qap_ms"] / K, 3), "ntt_x6_join": round(acc["ntt_ms"] / K, 3),
                           "msm_A_B1_B2_C_H": [round(x / K, 3) for x in acc["msm_ms"]],

@@ -122,6 +122,18 @@ int g16_prove_finish(g16_prover* p, uint32_t slot, const uint8_t* partials, uint
 int g16_shard_begin(g16_prover* p, uint32_t slot, uint32_t vec_mask, void* const out_vecs[3]);
 int g16_shard_end(g16_prover* p, uint32_t slot, const void* const slices[3], uint8_t partial[G16_PARTIAL_BYTES]);
 
+/* One PROCESS, several GPUs (the Node.js host of BASELINE config 4): a g16_multi owns one sharded handle per
+ * entry of `devices` (an ordinal may repeat: several shards on one GPU) and g16_multi_prove runs the sharded
+ * pipeline above on one host thread per shard, moving the slices between devices with peer copies and adding the
+ * partial sums on the host.  Same results and error texts as g16_prove.  opts: device / shard_* are ignored. */
+typedef struct g16_multi g16_multi;
+int g16_multi_create(const uint8_t* zkey, size_t zkey_len, const int32_t* devices, uint32_t ndev,
+                     const g16_opts* opts, g16_multi** out);
+int g16_multi_prove(g16_multi* m, const uint8_t* wtns, size_t wtns_len, const uint8_t r[32], const uint8_t s[32],
+                    g16_proof* out, uint8_t* pub);
+int g16_multi_get_info(const g16_multi* m, g16_info* out, uint32_t* n_shards);
+void g16_multi_destroy(g16_multi* m);
+
 /* Host-only assembly from gathered partials (no GPU handle needed; reads only the zkey header),
  * and the shard -> point-range map used by g16_create. */
 int g16_finish_host(const uint8_t* zkey, size_t zkey_len, const uint8_t* partials, uint32_t count,

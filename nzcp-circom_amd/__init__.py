@@ -56,7 +56,8 @@ EXPORTS = ["g16_create", "g16_prove", "g16_prove_batch", "g16_stage_witness", "g
            "g16_ec_add", "g16_g1_multiexp", "g16_g2_multiexp", "g16_synth_setup",
            "g16_synth_witness", "g16_free", "g16_finish_host", "g16_shard_range", "g16_r1cs_setup",
            "g16_sha256_chain_setup", "g16_sha256_message_setup", "g16_nzcp_fixed_layout_setup",
-           "g16_f29_op", "g16_x29_op", "g16_qap_eval", "g16_shard_begin", "g16_shard_end"]
+           "g16_f29_op", "g16_x29_op", "g16_qap_eval", "g16_shard_begin", "g16_shard_end",
+           "g16_multi_create", "g16_multi_prove", "g16_multi_get_info", "g16_multi_destroy"]
 
 
 def load():
@@ -92,6 +93,11 @@ def load():
     lib.g16_qap_eval.argtypes = [vp, C.c_uint32, C.c_char_p, C.c_char_p, C.c_char_p]
     lib.g16_shard_begin.argtypes = [vp, C.c_uint32, C.c_uint32, C.POINTER(vp)]
     lib.g16_shard_end.argtypes = [vp, C.c_uint32, C.POINTER(vp), C.c_char_p]
+    lib.g16_multi_create.argtypes = [C.c_char_p, sz, C.POINTER(C.c_int32), C.c_uint32, C.POINTER(Opts), C.POINTER(vp)]
+    lib.g16_multi_prove.argtypes = [vp, C.c_char_p, sz, C.c_char_p, C.c_char_p, C.POINTER(Proof), C.c_char_p]
+    lib.g16_multi_get_info.argtypes = [vp, C.POINTER(Info), C.POINTER(C.c_uint32)]
+    lib.g16_multi_destroy.argtypes = [vp]
+    lib.g16_multi_destroy.restype = None
     lib.g16_g1_multiexp.argtypes = [C.c_int, C.c_char_p, C.c_char_p, sz, C.c_int, C.c_char_p]
     lib.g16_g2_multiexp.argtypes = [C.c_int, C.c_char_p, C.c_char_p, sz, C.c_int, C.c_char_p]
     lib.g16_synth_setup.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint64, C.c_int,
@@ -237,12 +243,48 @@ class Prover:
                 "msm_accum_kernel_ms": list(t.msm_accum_kernel_ms)}
 
 
+class MultiProver:
+    """One process, several GPUs: one shard of the key per entry of `devices` (g16_multi_*)."""
+
+    def __init__(self, zkey, devices, window_bits=0, task_len=0):
+        lib = load()
+        self._h = C.c_void_p()
+        opts = Opts(0, 0, 1, window_bits, task_len, 0)
+        devs = (C.c_int32 * len(devices))(*devices)
+        _check(lib.g16_multi_create(zkey, len(zkey), devs, len(devices), C.byref(opts), C.byref(self._h)))
+        self.info = Info()
+        ns = C.c_uint32()
+        _check(lib.g16_multi_get_info(self._h, C.byref(self.info), C.byref(ns)))
+        self.n_shards = ns.value
+
+    def prove(self, wtns, r=None, s=None):
+        pr, pub = Proof(), C.create_string_buffer(max(1, self.info.n_public * 32))
+        _check(load().g16_multi_prove(self._h, wtns, len(wtns), r, s, C.byref(pr), pub))
+        p = self.info.n_public
+        return proof_to_obj(pr), [_dec(pub.raw[i * 32:(i + 1) * 32]) for i in range(p)]
+
+    def prove_raw(self, wtns, r, s, pr, pub):
+        return load().g16_multi_prove(self._h, wtns, len(wtns), r, s, C.byref(pr), pub)
+
+    def close(self):
+        if getattr(self, "_h", None) and self._h.value:
+            load().g16_multi_destroy(self._h)
+            self._h = C.c_void_p()
+
+    __del__ = close
+
+
 def finish_host(zkey, partials, r, s):
     """Assemble a proof from gathered partial-sum blobs on the host (no GPU handle)."""
     pr = Proof()
     blob = b"".join(partials)
     _check(load().g16_finish_host(zkey, len(zkey), blob, len(partials), r, s, C.byref(pr)))
     return proof_to_obj(pr)
+
+
+def shard_vector_owner(v, count):
+    """Sharded H pipeline: the shard that evaluates vector v (0 = A, 1 = B, 2 = C) on the coset."""
+    return v % count
 
 
 def shard_range(total, rank, count):

@@ -114,7 +114,8 @@ struct MsmGroup {
   uint32_t low_bits = 0, bins = 1;   // bucket = bin << low_bits | low: the two levels of the sort
   bool ones = false;            // extra unweighted row per section for the scalars equal to 1 (witness groups)
   uint32_t rps = 0, rows = 0;   // rows per section (W + ones), rows in total
-  uint32_t task_len = 0;
+  uint32_t task_len = 0;        // of the G1 lane
+  bool task_len_forced = false; // MsmConfig::task_len given: every lane uses it
   bool dense = true;
   uint32_t chunks = 1, per = 0; // front-end geometry: workgroups over the points, points per workgroup
   uint64_t max_entries = 0;     // upper bound on sorted entries of one launch
@@ -133,9 +134,15 @@ struct MsmResult {
 // (st2 == nullptr or == st: same stream).  msm_collect waits for both, folds the window sums on the host
 // (Horner, c doublings per row) and fills `out`.  One launch in flight per workspace.
 int msm_launch(const MsmGroup& g, MsmWorkspace* ws, const Fr* d_scalars, hipStream_t st, hipStream_t st2);
+// the same in two steps, so that a caller can order the lanes of one group after events of another:
+// gate1 / gate2 (optional) hold back the G1 / G2 bucket-accumulate kernel
+int msm_launch_front(const MsmGroup& g, MsmWorkspace* ws, const Fr* d_scalars, hipStream_t st);
+int msm_launch_lanes(const MsmGroup& g, MsmWorkspace* ws, hipStream_t st, hipStream_t st2, hipEvent_t gate1,
+                     hipEvent_t gate2);
+hipEvent_t msm_event(MsmWorkspace* ws, int which);   // 0 = sort done, 1 / 2 = G1 accumulate kernel started / done
 int msm_collect(const MsmGroup& g, MsmWorkspace* ws, MsmResult* out);
 float msm_last_accum_ms(const MsmWorkspace* ws, int lane);        // lane 0 = G1, 1 = G2: the accumulate kernel alone
-void msm_set_waves(MsmWorkspace* ws, uint32_t waves_per_simd);    // persistent accumulate grid (0 = full occupancy)
+void msm_set_waves(MsmWorkspace* ws, uint32_t waves_g1, uint32_t waves_g2);   // persistent accumulate grids, wavefronts per SIMD (0 = full occupancy)
 float msm_event_offset_ms(MsmWorkspace* ws, hipEvent_t base, int lane, int which);   // G16_TRACE_HOST timeline
 
 // total = sum_j 2^(c j) * windows[j]  (Horner, c doublings per window) [+ the unweighted ones row]

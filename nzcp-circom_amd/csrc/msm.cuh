@@ -63,7 +63,15 @@ struct MsmLaneWs {
   uint32_t point_base = 0;           // subtracted from a sorted entry to index this lane's base table
   uint32_t rows = 0;                 // (key_hi - key_lo) / B
   uint64_t max_tasks = 0;
-  uint2* d_task_desc = nullptr;      // by task id (relative to the lane's first task)
+  uint32_t task_len = 0;             // entries per task in THIS lane (the G2 lane has fewer lanes to fill and cuts shorter)
+  uint32_t seg_len = 0;              // buckets per reduce segment
+  uint32_t* d_off = nullptr;         // [nbk + 1] first sorted entry of a bucket (absolute position in d_sorted)
+  uint32_t* d_toff = nullptr;        // [nbk + 1] exclusive scan of ceil(cnt / task_len): first task id of a bucket
+  uint32_t* d_foff = nullptr;        // [nbk + 1] exclusive scan of floor(cnt / task_len): full-length tasks
+  uint32_t* d_tile_a = nullptr;
+  uint32_t* d_tile_b = nullptr;
+  uint32_t* d_tile_c = nullptr;
+  uint2* d_task_desc = nullptr;      // by task id
   uint4* d_qdesc = nullptr;          // by queue position: full-length tasks first
   uint32_t* d_class = nullptr;       // [2][kRemClasses]: remainder-class totals and cursors
   uint32_t* d_queue = nullptr;       // [0] work-queue head of the accumulate kernel, [1] number of flagged tasks
@@ -81,6 +89,9 @@ struct MsmLaneWs {
   hipEvent_t ev_done = nullptr;
   hipEvent_t trace_ev[4] = {};       // G16_TRACE_HOST: queue built, combined, reduced, end
   float last_accum_ms = 0.f;
+  // scheduling of the next launch (msm_launch_lanes / msm_set_waves)
+  hipEvent_t gate = nullptr;         // the accumulate kernel waits for this event (nullptr: none)
+  uint32_t waves_per_simd = 0;       // persistent accumulate grid, 0 = the kernel's full occupancy
 };
 
 struct MsmWorkspace {
@@ -91,41 +102,34 @@ struct MsmWorkspace {
   uint2* d_tmp = nullptr;            // binned entries: (table index | sign << 31, low bucket bits)
   uint32_t* d_sorted = nullptr;      // final list: table index | sign << 31, grouped by bucket key
   uint32_t* d_cnt = nullptr;         // [nb] bucket populations
-  uint32_t* d_off = nullptr;         // [nb + 1] exclusive scan of cnt
-  uint32_t* d_toff = nullptr;        // [nb + 1] exclusive scan of ceil(cnt / task_len): first task id of a bucket
-  uint32_t* d_foff = nullptr;        // [nb + 1] exclusive scan of floor(cnt / task_len): full-length tasks
-  uint32_t* d_tile_a = nullptr;
-  uint32_t* d_tile_b = nullptr;
-  uint32_t* d_tile_c = nullptr;
   uint32_t nb = 0;
   MsmLaneWs lane[2];
   hipEvent_t ev_sorted = nullptr;    // sort + scans done: the lanes may start
-  hipEvent_t trace_ev[4] = {};       // G16_TRACE_HOST: pass 0, bin scans, pass 1, bin sort + scans
-  uint32_t waves_per_simd = 0;       // persistent accumulate grid, 0 = the kernel's full occupancy
+  hipEvent_t trace_ev[4] = {};       // G16_TRACE_HOST: pass 0, bin scans, pass 1, bin sort
   bool launched = false;
   bool empty = false;                // the last launch had no points
 };
 
 struct U256 { uint32_t v[8]; };
 
-static constexpr uint32_t kSegLenDefault = 16;   // buckets per reduce segment (G16_SEG_LEN overrides, sweeps)
-// `dense` (the H-MSM): its reduce is the exposed tail of the proof, so shorter segments (more lanes, shorter
-// chains) pay; the witness group reduces while the H-MSM accumulates, where extra VALU work only competes.
-inline uint32_t msm_seg_len(bool dense = false) {
-  struct Cfg { uint32_t v, vd; };
+// Buckets per reduce segment: a lane sums its segment with running sums (2 additions per bucket) and weights it
+// with a short double-and-add; shorter segments = more lanes and shorter chains on a latency-bound kernel.
+// which: 0 = witness group G1 lane, 1 = G2 lane, 2 = dense (H).  G16_SEG_LEN="w,g2,h" overrides (sweeps).
+inline uint32_t msm_seg_len_cfg(int which) {
+  struct Cfg { uint32_t v[3]; };
   static const Cfg cfg = [] {   // thread-safe one-time initialisation (two host threads may prove on two handles)
-    Cfg c;
-    const char* e = getenv("G16_SEG_LEN");
-    c.v = e ? (uint32_t)atoi(e) : kSegLenDefault;
-    if (c.v < 1) c.v = 1;
-    if (c.v > 64) c.v = 64;
-    const char* ed = getenv("G16_SEG_LEN_DENSE");
-    c.vd = ed ? (uint32_t)atoi(ed) : (e ? c.v : 8u);
-    if (c.vd < 1) c.vd = 1;
-    if (c.vd > 64) c.vd = 64;
+    Cfg c{{8u, 4u, 8u}};
+    if (const char* e = getenv("G16_SEG_LEN")) {
+      int a = 0, b = 0, d = 0;
+      const int k = sscanf(e, "%d,%d,%d", &a, &b, &d);
+      if (k >= 1 && a > 0) c.v[0] = (uint32_t)a;
+      if (k >= 2 && b > 0) c.v[1] = (uint32_t)b;
+      if (k >= 3 && d > 0) c.v[2] = (uint32_t)d;
+    }
+    for (auto& x : c.v) x = x > 64 ? 64 : x;
     return c;
   }();
-  return dense ? cfg.vd : cfg.v;
+  return cfg.v[which];
 }
 
 static constexpr uint32_t kRemClasses = 32;   // remainder tasks are queued by relative length, longest class first
@@ -151,13 +155,13 @@ int msm_precompute_g2(const void* in, void* out, uint32_t n, int ndbl);
 template <class F>
 __global__ __launch_bounds__(64, F::kAccumWavesPerSimd) void msm_accumulate_kernel(const PackedAffine<F>* __restrict__ bases,
                                                             const uint32_t* __restrict__ sorted,
-                                                            const uint32_t* __restrict__ toff, uint32_t key_lo,
-                                                            uint32_t key_hi, uint32_t point_base,
+                                                            const uint32_t* __restrict__ toff, uint32_t nbk,
+                                                            uint32_t point_base,
                                                             const uint4* __restrict__ qdesc,
                                                             uint32_t* __restrict__ queue,
                                                             uint32_t* __restrict__ redo,
                                                             XYZZ<F>* __restrict__ partial) {
-  const uint32_t total = toff[key_hi] - toff[key_lo];
+  const uint32_t total = toff[nbk];
   const uint32_t lane = threadIdx.x;
   const unsigned long long lt_mask = (1ull << lane) - 1;
   constexpr uint32_t kNone = 0xffffffffu;
@@ -279,19 +283,18 @@ template <class F> __device__ __forceinline__ XYZZ<F> xyzz_shfl_down(const XYZZ<
   return r;
 }
 
-// Buckets cut into SEVERAL tasks: bsum[b - key_lo] = sum of the task partials of bucket b (2 .. light_max
+// Buckets cut into SEVERAL tasks: bsum[b] = sum of the task partials of bucket b (2 .. light_max
 // partials: a lane per bucket; more: queued for the wavefront kernel).  A bucket with one task needs no pass at
 // all -- the reduce kernel reads its partial sum directly (msm_bucket_value).
 template <class F>
 __global__ __launch_bounds__(64) void msm_combine_light_kernel(const XYZZ<F>* __restrict__ partial,
-                                                               const uint32_t* __restrict__ toff, uint32_t key_lo,
-                                                               uint32_t key_hi, XYZZ<F>* __restrict__ bsum,
+                                                               const uint32_t* __restrict__ toff, uint32_t nbk,
+                                                               XYZZ<F>* __restrict__ bsum,
                                                                uint32_t* __restrict__ heavy, uint32_t max_heavy,
                                                                uint32_t light_max) {
-  const uint32_t b = key_lo + blockIdx.x * blockDim.x + threadIdx.x;
-  if (b >= key_hi) return;
-  const uint32_t tb = toff[key_lo];
-  const uint32_t t0 = toff[b] - tb, t1 = toff[b + 1] - tb;
+  const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= nbk) return;
+  const uint32_t t0 = toff[b], t1 = toff[b + 1];
   if (t1 - t0 < 2) return;
   if (t1 - t0 > light_max) {
     const uint32_t k = atomicAdd(&heavy[0], 1u);
@@ -303,22 +306,21 @@ __global__ __launch_bounds__(64) void msm_combine_light_kernel(const XYZZ<F>* __
     const XYZZ<F> s = partial[t];
     x29_add(acc, s);
   }
-  bsum[b - key_lo] = acc;
+  bsum[b] = acc;
 }
 
 // One wavefront per heavy bucket: lanes stride over the partials, then a 6-step shuffle tree.
 template <class F>
 __global__ __launch_bounds__(64) void msm_combine_heavy_kernel(const XYZZ<F>* __restrict__ partial,
-                                                               const uint32_t* __restrict__ toff, uint32_t key_lo,
+                                                               const uint32_t* __restrict__ toff,
                                                                XYZZ<F>* __restrict__ bsum,
                                                                const uint32_t* __restrict__ heavy, uint32_t max_heavy) {
   uint32_t count = heavy[0];
   if (count > max_heavy) count = max_heavy;
   const uint32_t lane = threadIdx.x;
-  const uint32_t tb = toff[key_lo];
   for (uint32_t h = blockIdx.x; h < count; h += gridDim.x) {
     const uint32_t b = heavy[1 + h];
-    const uint32_t t0 = toff[b] - tb, t1 = toff[b + 1] - tb;
+    const uint32_t t0 = toff[b], t1 = toff[b + 1];
     XYZZ<F> acc;
     x29_set_inf(acc);
     for (uint32_t t = t0 + lane; t < t1; t += 64) {
@@ -329,30 +331,29 @@ __global__ __launch_bounds__(64) void msm_combine_heavy_kernel(const XYZZ<F>* __
       const XYZZ<F> q = xyzz_shfl_down(acc, d);
       x29_add(acc, q);
     }
-    if (lane == 0) bsum[b - key_lo] = acc;
+    if (lane == 0) bsum[b] = acc;
   }
 }
 
-// the sum of bucket b: nothing, its single task's partial sum, or the combined sum
+// the sum of bucket b (lane-local index): nothing, its single task's partial sum, or the combined sum
 template <class F>
 __device__ __forceinline__ XYZZ<F> msm_bucket_value(const XYZZ<F>* __restrict__ partial, const XYZZ<F>* __restrict__ bsum,
-                                                    const uint32_t* __restrict__ toff, uint32_t tb, uint32_t key_lo,
-                                                    uint32_t b) {
+                                                    const uint32_t* __restrict__ toff, uint32_t b) {
   const uint32_t t0 = toff[b], nt = toff[b + 1] - t0;
   if (nt == 0) {
     XYZZ<F> z;
     x29_set_inf(z);
     return z;
   }
-  if (nt == 1) return partial[t0 - tb];
-  return bsum[b - key_lo];
+  if (nt == 1) return partial[t0];
+  return bsum[b];
 }
 
 // seg[j*nseg + g] = sum_{bi in segment g of row j} (bi+1) * S_bi;  ones rows (j % rps == W): plain sum S_bi
 template <class F>
 __global__ __launch_bounds__(64) void msm_bucket_reduce_kernel(const XYZZ<F>* __restrict__ partial,
                                                                const XYZZ<F>* __restrict__ bsum,
-                                                               const uint32_t* __restrict__ toff, uint32_t key_lo,
+                                                               const uint32_t* __restrict__ toff,
                                                                uint32_t B, uint32_t nseg, uint32_t rows, uint32_t rps,
                                                                uint32_t W, uint32_t ones, uint32_t seg_len,
                                                                XYZZ<F>* __restrict__ seg) {
@@ -362,12 +363,11 @@ __global__ __launch_bounds__(64) void msm_bucket_reduce_kernel(const XYZZ<F>* __
   const bool plain = ones && (j % rps == W);   // the "ones" pseudo-window: plain sum of its buckets
   const uint32_t lo = g * seg_len;
   const uint32_t hi = (lo + seg_len < B) ? lo + seg_len : B;
-  const uint32_t tb = toff[key_lo];
   XYZZ<F> run, acc;
   x29_set_inf(run);
   x29_set_inf(acc);
   for (uint32_t bi = hi; bi-- > lo;) {
-    const XYZZ<F> s = msm_bucket_value<F>(partial, bsum, toff, tb, key_lo, key_lo + j * B + bi);
+    const XYZZ<F> s = msm_bucket_value<F>(partial, bsum, toff, j * B + bi);
     x29_add(run, s);
     if (!plain) x29_add(acc, run);
   }
@@ -461,31 +461,32 @@ int msm_launch_lane_t(const MsmGroup& g, MsmWorkspace* ws, MsmLaneWs& ln, const 
   if (rc) return rc;
   mark(0);
   const uint32_t nbk = ln.key_hi - ln.key_lo;
-  const uint32_t seg_len = msm_seg_len(g.dense);
+  const uint32_t seg_len = ln.seg_len;
   const uint32_t nseg = (g.B + seg_len - 1) / seg_len;
   // persistent grid: as many wavefronts as the chip holds for this kernel (4/SIMD G1, 2/SIMD G2), fewer
   // when there is little work
   const uint32_t full_occ = (uint32_t)F::kAccumWavesPerSimd;
-  const uint32_t occ = (ws->waves_per_simd && ws->waves_per_simd < full_occ) ? ws->waves_per_simd : full_occ;
+  const uint32_t occ = (ln.waves_per_simd && ln.waves_per_simd < full_occ) ? ln.waves_per_simd : full_occ;
   uint64_t waves = (uint64_t)256 * 4 * occ;
   if (waves > (ln.max_tasks + kTaskChunk - 1) / kTaskChunk) waves = (ln.max_tasks + kTaskChunk - 1) / kTaskChunk;
   if (waves == 0) waves = 1;
   G16_HIP(hipMemsetAsync(ln.d_queue, 0, 8, st));
+  if (ln.gate) G16_HIP(hipStreamWaitEvent(st, ln.gate, 0));
   G16_HIP(hipEventRecord(ln.ev0, st));
-  msm_accumulate_kernel<F><<<(unsigned)waves, 64, 0, st>>>((const PackedAffine<F>*)d_bases, ws->d_sorted, ws->d_toff, ln.key_lo,
-                                                            ln.key_hi, ln.point_base, ln.d_qdesc, ln.d_queue, ln.d_redo,
+  msm_accumulate_kernel<F><<<(unsigned)waves, 64, 0, st>>>((const PackedAffine<F>*)d_bases, ws->d_sorted, ln.d_toff, nbk,
+                                                            ln.point_base, ln.d_qdesc, ln.d_queue, ln.d_redo,
                                                             (PT*)ln.d_partial);
   G16_HIP(hipEventRecord(ln.ev1, st));
   msm_redo_kernel<F><<<64, 64, 0, st>>>((const PackedAffine<F>*)d_bases, ws->d_sorted, ln.point_base, ln.d_task_desc,
                                         ln.d_queue, ln.d_redo, (PT*)ln.d_partial);
   G16_HIP(hipMemsetAsync(ln.d_heavy, 0, 4, st));
-  msm_combine_light_kernel<F><<<(nbk + 63) / 64, 64, 0, st>>>((const PT*)ln.d_partial, ws->d_toff, ln.key_lo, ln.key_hi,
+  msm_combine_light_kernel<F><<<(nbk + 63) / 64, 64, 0, st>>>((const PT*)ln.d_partial, ln.d_toff, nbk,
                                                               (PT*)ln.d_bsum, ln.d_heavy, ln.max_heavy, msm_light_max(ln));
-  msm_combine_heavy_kernel<F><<<1024, 64, 0, st>>>((const PT*)ln.d_partial, ws->d_toff, ln.key_lo, (PT*)ln.d_bsum,
+  msm_combine_heavy_kernel<F><<<1024, 64, 0, st>>>((const PT*)ln.d_partial, ln.d_toff, (PT*)ln.d_bsum,
                                                    ln.d_heavy, ln.max_heavy);
   mark(1);
   msm_bucket_reduce_kernel<F><<<(ln.rows * nseg + 63) / 64, 64, 0, st>>>((const PT*)ln.d_partial, (const PT*)ln.d_bsum,
-                                                                        ws->d_toff, ln.key_lo, g.B, nseg, ln.rows, g.rps,
+                                                                        ln.d_toff, g.B, nseg, ln.rows, g.rps,
                                                                         (uint32_t)g.W, g.ones ? 1u : 0u, seg_len,
                                                                         (PT*)ln.d_seg);
   mark(2);

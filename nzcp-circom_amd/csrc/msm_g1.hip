@@ -265,6 +265,7 @@ static __global__ __launch_bounds__(256) void msm_scan_tiles_kernel(const uint32
 static __global__ __launch_bounds__(1024) void msm_scan_top_kernel(uint32_t* __restrict__ tile_a,
                                                             uint32_t* __restrict__ tile_b,
                                                             uint32_t* __restrict__ tile_c, uint32_t ntiles,
+                                                            const uint32_t* __restrict__ off_base,
                                                             uint32_t* __restrict__ total_a,
                                                             uint32_t* __restrict__ total_b,
                                                             uint32_t* __restrict__ total_c) {
@@ -289,13 +290,14 @@ static __global__ __launch_bounds__(1024) void msm_scan_top_kernel(uint32_t* __r
     tile_a[k] = pa; tile_b[k] = pb; tile_c[k] = pc;
     pa += va; pb += vb; pc += vc;
   }
-  if (tid == 1023) { *total_a = sh_a[1023]; *total_b = sh_b[1023]; *total_c = sh_c[1023]; }
+  if (tid == 1023) { *total_a = *off_base + sh_a[1023]; *total_b = sh_b[1023]; *total_c = sh_c[1023]; }
 }
 
 static __global__ __launch_bounds__(256) void msm_scan_apply_kernel(const uint32_t* __restrict__ cnt, uint32_t nb,
                                                              uint32_t tl, const uint32_t* __restrict__ tile_a,
                                                              const uint32_t* __restrict__ tile_b,
                                                              const uint32_t* __restrict__ tile_c,
+                                                             const uint32_t* __restrict__ off_base,
                                                              uint32_t* __restrict__ off,
                                                              uint32_t* __restrict__ toff,
                                                              uint32_t* __restrict__ foff) {
@@ -318,7 +320,7 @@ static __global__ __launch_bounds__(256) void msm_scan_apply_kernel(const uint32
     sh_a[tid] += va; sh_b[tid] += vb; sh_c[tid] += vc;
     __syncthreads();
   }
-  uint32_t pa = tile_a[blockIdx.x] + sh_a[tid] - sa, pb = tile_b[blockIdx.x] + sh_b[tid] - sb,
+  uint32_t pa = *off_base + tile_a[blockIdx.x] + sh_a[tid] - sa, pb = tile_b[blockIdx.x] + sh_b[tid] - sb,
            pc = tile_c[blockIdx.x] + sh_c[tid] - sc;
 #pragma unroll
   for (int k = 0; k < 8; k++) {
@@ -340,20 +342,19 @@ static __global__ __launch_bounds__(256) void msm_scan_apply_kernel(const uint32
 // wavefront then start and finish their full tasks in the same iteration, so the flush / start / request code
 // of the accumulate loop runs once per task instead of in nearly every iteration, and the queue ends with its
 // shortest tasks (a shorter drain).  qdesc[q] = (first entry, count, task id, -).  Task ids and queue positions
-// are relative to the lane's key range [key_lo, key_hi).
+// are local to the lane (its key range [key_lo, key_hi) of the group, its own task length).
 __device__ __forceinline__ uint32_t msm_rem_class(uint32_t len, uint32_t task_len) {
   return (len * kRemClasses) / task_len;      // len < task_len -> 0 .. kRemClasses - 1
 }
 
 // class_total[c] = number of remainder tasks (cnt % task_len != 0) of relative-length class c
-static __global__ __launch_bounds__(256) void msm_rem_count_kernel(const uint32_t* __restrict__ cnt, uint32_t key_lo,
-                                                            uint32_t key_hi, uint32_t tl,
-                                                            uint32_t* __restrict__ class_total) {
+static __global__ __launch_bounds__(256) void msm_rem_count_kernel(const uint32_t* __restrict__ cnt, uint32_t nbk,
+                                                            uint32_t tl, uint32_t* __restrict__ class_total) {
   __shared__ uint32_t h[kRemClasses];
   if (threadIdx.x < kRemClasses) h[threadIdx.x] = 0;
   __syncthreads();
-  const uint32_t b = key_lo + blockIdx.x * blockDim.x + threadIdx.x;
-  if (b < key_hi) {
+  const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b < nbk) {
     const uint32_t r = cnt[b] % tl;
     if (r) atomicAdd(&h[msm_rem_class(r, tl)], 1u);
   }
@@ -363,8 +364,8 @@ static __global__ __launch_bounds__(256) void msm_rem_count_kernel(const uint32_
 
 static __global__ __launch_bounds__(256) void msm_task_fill_kernel(const uint32_t* __restrict__ off,
                                                             const uint32_t* __restrict__ toff,
-                                                            const uint32_t* __restrict__ foff, uint32_t key_lo,
-                                                            uint32_t key_hi, uint32_t task_len,
+                                                            const uint32_t* __restrict__ foff, uint32_t nbk,
+                                                            uint32_t task_len,
                                                             uint2* __restrict__ task_desc, uint4* __restrict__ qdesc,
                                                             const uint32_t* __restrict__ class_total,
                                                             uint32_t* __restrict__ class_cursor) {
@@ -373,10 +374,9 @@ static __global__ __launch_bounds__(256) void msm_task_fill_kernel(const uint32_
   __shared__ uint32_t h[kRemClasses], base[kRemClasses];
   if (threadIdx.x < kRemClasses) h[threadIdx.x] = 0;
   __syncthreads();
-  const uint32_t b = key_lo + blockIdx.x * blockDim.x + threadIdx.x;
-  const uint32_t tb = toff[key_lo], fb = foff[key_lo];
+  const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
   uint32_t start = 0, left = 0, rem = 0, cls = 0, rank = 0;
-  if (b < key_hi) {
+  if (b < nbk) {
     start = off[b];
     left = off[b + 1] - start;
     rem = left % task_len;
@@ -388,14 +388,14 @@ static __global__ __launch_bounds__(256) void msm_task_fill_kernel(const uint32_
   __syncthreads();
   if (threadIdx.x < kRemClasses) {
     const uint32_t c = threadIdx.x;
-    uint32_t before = foff[key_hi] - fb;                       // all full tasks, then the longer classes
+    uint32_t before = foff[nbk];                               // all full tasks, then the longer classes
     for (uint32_t k = c + 1; k < kRemClasses; k++) before += class_total[k];
     base[c] = h[c] ? before + atomicAdd(&class_cursor[c], h[c]) : 0u;
   }
   __syncthreads();
-  if (b >= key_hi) return;
-  uint32_t fq = foff[b] - fb;
-  for (uint32_t t = toff[b] - tb, e = toff[b + 1] - tb; t < e; t++) {
+  if (b >= nbk) return;
+  uint32_t fq = foff[b];
+  for (uint32_t t = toff[b], e = toff[b + 1]; t < e; t++) {
     const uint32_t len = left < task_len ? left : task_len;
     task_desc[t] = make_uint2(start, len);
     qdesc[len == task_len ? fq++ : base[cls] + rank] = make_uint4(start, len, t, 0u);
@@ -582,19 +582,31 @@ int msm_group_create(MsmGroup& g, const MsmSectionIn* secs, int nsec, const MsmC
   g.rows = (uint32_t)nsec * g.rps;
   // two-level sort: bucket = bin << low_bits | low; 8 low bits unless that leaves too many (row, bin) counters
   // for the LDS of the binning passes (<= 12288)
-  g.low_bits = (uint32_t)(g.c - 1) < 8u ? (uint32_t)(g.c - 1) : 8u;
+  // (witness groups: 6 -- their bins are uneven (small scalars crowd the low buckets of window 0, r02: the largest
+  // bin 3x the average), and one workgroup sorts one bin)
+  uint32_t want_low = cfg.dense ? 8u : 6u;
+  if (const char* e = getenv("G16_LOW_BITS")) {
+    int a = 0, b = 0;
+    const int k = sscanf(e, "%d,%d", &a, &b);
+    if (!cfg.dense && k >= 1 && a > 0) want_low = (uint32_t)a;
+    if (cfg.dense && k >= 2 && b > 0) want_low = (uint32_t)b;
+  }
+  g.low_bits = (uint32_t)(g.c - 1) < want_low ? (uint32_t)(g.c - 1) : want_low;
   while (g.low_bits < kMaxLowBits && (uint64_t)g.rows * (g.B >> g.low_bits) > 12288) g.low_bits++;
   g.bins = g.B >> g.low_bits;
   if ((uint64_t)g.rows * g.bins > 12288) { set_error("msm: window bits too large for this group"); return G16_E_ARG; }
-  // Task length: enough tasks to fill ~256k lanes (256 CUs x 4 SIMDs x 4 waves x 64), within [16, 32]: short
-  // tasks keep the drain tail of the persistent kernel small (sweep r01)
+  // Task length of the G1 lane (the G2 lane derives its own in lane_create): enough tasks to fill ~256k lanes
+  // (256 CUs x 4 SIMDs x 4 waves x 64), within [16, 32]: short tasks keep the drain tail of the persistent kernel
+  // small (sweep r01)
   if (cfg.task_len) {
     g.task_len = (uint32_t)cfg.task_len;
   } else {
-    const uint64_t entries = (uint64_t)n_eff * g.Ws * (uint32_t)nsec;
+    uint64_t entries = 0;
+    for (int s = 0; s < nsec; s++) entries += (uint64_t)(cfg.dense ? g.sec_n[s] : g.sec_n[s] / 3 + 1) * g.Ws;
     const uint64_t t = entries / 262144;
     g.task_len = (uint32_t)(t < 16 ? 16 : (t > 32 ? 32 : t));
   }
+  g.task_len_forced = cfg.task_len != 0;
   g.max_entries = (uint64_t)g.n * (uint32_t)g.Ws;
   if (g.max_entries >= 0x7fffffffull) { set_error("msm: too many bucket entries"); return G16_E_ARG; }
   // front-end chunks: >= 4096 points per 256-thread workgroup (long (row, bin) runs), at most 1024 workgroups
@@ -628,7 +640,7 @@ void msm_group_destroy(MsmGroup& g) {
 }
 
 static int lane_create(MsmLaneWs& ln, const MsmGroup& g, int curve, uint32_t key_lo, uint32_t key_hi, uint32_t point_base,
-                       uint64_t entries) {
+                       uint64_t entries, uint64_t entries_eff) {
   ln.active = true;
   ln.curve = curve;
   ln.key_lo = key_lo;
@@ -636,12 +648,25 @@ static int lane_create(MsmLaneWs& ln, const MsmGroup& g, int curve, uint32_t key
   ln.point_base = point_base;
   ln.rows = (key_hi - key_lo) / g.B;
   const uint64_t nbk = (uint64_t)key_hi - key_lo;
+  // task length: fill the lane's persistent grid (G1: 4 wavefronts per SIMD = 262144 lanes, G2: 2 = 131072)
+  ln.task_len = g.task_len;
+  if (curve == 2 && !g.task_len_forced) {
+    const uint64_t t = entries_eff / 131072;
+    ln.task_len = (uint32_t)(t < 8 ? 8 : (t > 32 ? 32 : t));
+  }
+  ln.seg_len = msm_seg_len_cfg(curve == 2 ? 1 : (g.dense ? 2 : 0));
   // every non-empty bucket has <= 1 short task + entries / task_len full ones
-  ln.max_tasks = nbk + entries / g.task_len + 64;
+  ln.max_tasks = nbk + entries / ln.task_len + 64;
   const size_t pb = curve == 2 ? sizeof(G2XYZZ29) : sizeof(G1XYZZ29);   // device-side (lazy) points
   const size_t cpb = msm_point_bytes(curve);                             // canonical, host-visible
-  const uint32_t sl = msm_seg_len(true) < msm_seg_len(false) ? msm_seg_len(true) : msm_seg_len(false);
-  const uint64_t nseg = (g.B + sl - 1) / sl;
+  const uint64_t nseg = (g.B + ln.seg_len - 1) / ln.seg_len;
+  const size_t ntiles = (size_t)nbk / kScanTile + 2;
+  G16_HIP(hipMalloc(&ln.d_off, (nbk + 4) * 4));
+  G16_HIP(hipMalloc(&ln.d_toff, (nbk + 4) * 4));
+  G16_HIP(hipMalloc(&ln.d_foff, (nbk + 4) * 4));
+  G16_HIP(hipMalloc(&ln.d_tile_a, ntiles * 4));
+  G16_HIP(hipMalloc(&ln.d_tile_b, ntiles * 4));
+  G16_HIP(hipMalloc(&ln.d_tile_c, ntiles * 4));
   G16_HIP(hipMalloc(&ln.d_task_desc, (ln.max_tasks + 1) * sizeof(uint2)));
   G16_HIP(hipMalloc(&ln.d_qdesc, (ln.max_tasks + 1) * sizeof(uint4)));
   G16_HIP(hipMalloc(&ln.d_class, 2 * kRemClasses * 4));
@@ -664,7 +689,7 @@ static int lane_create(MsmLaneWs& ln, const MsmGroup& g, int curve, uint32_t key
 
 static void lane_destroy(MsmLaneWs& ln) {
   void* ptrs[] = {ln.d_task_desc, ln.d_qdesc, ln.d_class, ln.d_queue, ln.d_redo, ln.d_partial, ln.d_bsum, ln.d_heavy,
-                  ln.d_seg, ln.d_red, ln.d_canon};
+                  ln.d_seg, ln.d_red, ln.d_canon, ln.d_off, ln.d_toff, ln.d_foff, ln.d_tile_a, ln.d_tile_b, ln.d_tile_c};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   if (ln.h_pinned) (void)hipHostFree(ln.h_pinned);
@@ -680,34 +705,27 @@ int msm_workspace_create(MsmWorkspace** out, const MsmGroup& g) {
   if (g.n == 0) return G16_OK;
   const uint32_t nrb = g.rows * g.bins;
   ws->nb = g.rows * g.B;
-  const size_t ntiles = (size_t)ws->nb / kScanTile + 2;
   G16_HIP(hipMalloc(&ws->d_hist, ((size_t)g.chunks * nrb + 4) * 4));
   G16_HIP(hipMalloc(&ws->d_bin_cnt, ((size_t)nrb + 4) * 4));
   G16_HIP(hipMalloc(&ws->d_bin_start, ((size_t)nrb + 4) * 4));
   G16_HIP(hipMalloc(&ws->d_tmp, (g.max_entries + 4) * sizeof(uint2)));
   G16_HIP(hipMalloc(&ws->d_sorted, (g.max_entries + 4) * 4));
   G16_HIP(hipMalloc(&ws->d_cnt, ((size_t)ws->nb + 4) * 4));
-  G16_HIP(hipMalloc(&ws->d_off, ((size_t)ws->nb + 4) * 4));
-  G16_HIP(hipMalloc(&ws->d_toff, ((size_t)ws->nb + 4) * 4));
-  G16_HIP(hipMalloc(&ws->d_foff, ((size_t)ws->nb + 4) * 4));
-  G16_HIP(hipMalloc(&ws->d_tile_a, ntiles * 4));
-  G16_HIP(hipMalloc(&ws->d_tile_b, ntiles * 4));
-  G16_HIP(hipMalloc(&ws->d_tile_c, ntiles * 4));
   G16_HIP(hipEventCreate(&ws->ev_sorted));
   int rc = G16_OK;
-  if (g.d_bases) rc = lane_create(ws->lane[0], g, 1, 0, ws->nb, 0, g.max_entries);
+  const uint32_t div = g.dense ? 1 : 3;   // effective (full-width) share of the scalars
+  if (g.d_bases) rc = lane_create(ws->lane[0], g, 1, 0, ws->nb, 0, g.max_entries, g.max_entries / div);
   if (!rc && g.g2_sec >= 0) {
     const uint32_t lo = (uint32_t)g.g2_sec * g.rps * g.B;
-    rc = lane_create(ws->lane[1], g, 2, lo, lo + g.rps * g.B, g.pf > 1 ? 0u : g.sec_begin[g.g2_sec],
-                     (uint64_t)g.sec_n[g.g2_sec] * (uint32_t)g.Ws);
+    const uint64_t e2 = (uint64_t)g.sec_n[g.g2_sec] * (uint32_t)g.Ws;
+    rc = lane_create(ws->lane[1], g, 2, lo, lo + g.rps * g.B, g.pf > 1 ? 0u : g.sec_begin[g.g2_sec], e2, e2 / div);
   }
   return rc;
 }
 
 void msm_workspace_destroy(MsmWorkspace* ws) {
   if (!ws) return;
-  void* ptrs[] = {ws->d_hist, ws->d_bin_cnt, ws->d_bin_start, ws->d_tmp, ws->d_sorted, ws->d_cnt, ws->d_off, ws->d_toff,
-                  ws->d_foff, ws->d_tile_a, ws->d_tile_b, ws->d_tile_c};
+  void* ptrs[] = {ws->d_hist, ws->d_bin_cnt, ws->d_bin_start, ws->d_tmp, ws->d_sorted, ws->d_cnt};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   for (auto& ln : ws->lane) lane_destroy(ln);
@@ -719,7 +737,7 @@ void msm_workspace_destroy(MsmWorkspace* ws) {
 
 int msm_front_end(const MsmGroup& g, MsmWorkspace* ws, const Fr* d_scalars, hipStream_t st) {
   const MsmPlan pl = msm_plan_of(g);
-  const uint32_t nrb = g.rows * g.bins, nb = ws->nb;
+  const uint32_t nrb = g.rows * g.bins;
   U256 K;
   msm_make_K(g.c, g.Ws, K);
   static const bool trace = getenv("G16_TRACE_HOST") != nullptr;
@@ -739,49 +757,67 @@ int msm_front_end(const MsmGroup& g, MsmWorkspace* ws, const Fr* d_scalars, hipS
                                                              ws->d_bin_start, ws->d_tmp);
   mark(2);
   msm_bin_sort_kernel<<<nrb, 256, 0, st>>>(ws->d_tmp, ws->d_bin_start, pl, ws->d_cnt, ws->d_sorted);
-  const uint32_t ntiles = (nb + kScanTile - 1) / kScanTile;
-  msm_scan_tiles_kernel<<<ntiles, 256, 0, st>>>(ws->d_cnt, nb, g.task_len, ws->d_tile_a, ws->d_tile_b, ws->d_tile_c);
-  msm_scan_top_kernel<<<1, 1024, 0, st>>>(ws->d_tile_a, ws->d_tile_b, ws->d_tile_c, ntiles, ws->d_off + nb, ws->d_toff + nb,
-                                          ws->d_foff + nb);
-  msm_scan_apply_kernel<<<ntiles, 256, 0, st>>>(ws->d_cnt, nb, g.task_len, ws->d_tile_a, ws->d_tile_b, ws->d_tile_c,
-                                                ws->d_off, ws->d_toff, ws->d_foff);
   mark(3);
   G16_HIP(hipGetLastError());
   G16_HIP(hipEventRecord(ws->ev_sorted, st));
   return G16_OK;
 }
 
+// Per lane: exclusive scans of its bucket populations (entry offsets, task ids, queue positions of the full-length
+// tasks, for THIS lane's task length), then the task descriptors and the work queue.
 int msm_build_queue(const MsmGroup& g, MsmWorkspace* ws, MsmLaneWs& ln, hipStream_t st) {
   const uint32_t nbk = ln.key_hi - ln.key_lo;
+  const uint32_t* cnt = ws->d_cnt + ln.key_lo;
+  // the lane's first entry = the start of the first bin of its first row
+  const uint32_t* off_base = ws->d_bin_start + (size_t)(ln.key_lo / g.B) * g.bins;
+  const uint32_t ntiles = (nbk + kScanTile - 1) / kScanTile;
+  msm_scan_tiles_kernel<<<ntiles, 256, 0, st>>>(cnt, nbk, ln.task_len, ln.d_tile_a, ln.d_tile_b, ln.d_tile_c);
+  msm_scan_top_kernel<<<1, 1024, 0, st>>>(ln.d_tile_a, ln.d_tile_b, ln.d_tile_c, ntiles, off_base, ln.d_off + nbk,
+                                          ln.d_toff + nbk, ln.d_foff + nbk);
+  msm_scan_apply_kernel<<<ntiles, 256, 0, st>>>(cnt, nbk, ln.task_len, ln.d_tile_a, ln.d_tile_b, ln.d_tile_c, off_base,
+                                                ln.d_off, ln.d_toff, ln.d_foff);
   G16_HIP(hipMemsetAsync(ln.d_class, 0, 2 * kRemClasses * 4, st));
-  msm_rem_count_kernel<<<(nbk + 255) / 256, 256, 0, st>>>(ws->d_cnt, ln.key_lo, ln.key_hi, g.task_len, ln.d_class);
-  msm_task_fill_kernel<<<(nbk + 255) / 256, 256, 0, st>>>(ws->d_off, ws->d_toff, ws->d_foff, ln.key_lo, ln.key_hi, g.task_len,
-                                                          ln.d_task_desc, ln.d_qdesc, ln.d_class, ln.d_class + kRemClasses);
+  msm_rem_count_kernel<<<(nbk + 255) / 256, 256, 0, st>>>(cnt, nbk, ln.task_len, ln.d_class);
+  msm_task_fill_kernel<<<(nbk + 255) / 256, 256, 0, st>>>(ln.d_off, ln.d_toff, ln.d_foff, nbk, ln.task_len, ln.d_task_desc,
+                                                          ln.d_qdesc, ln.d_class, ln.d_class + kRemClasses);
   G16_HIP(hipGetLastError());
   return G16_OK;
 }
 
-int msm_launch(const MsmGroup& g, MsmWorkspace* ws, const Fr* d_scalars, hipStream_t st, hipStream_t st2) {
+int msm_launch_front(const MsmGroup& g, MsmWorkspace* ws, const Fr* d_scalars, hipStream_t st) {
   ws->launched = true;
   ws->empty = (g.n == 0);
   for (auto& ln : ws->lane) ln.last_accum_ms = 0.f;
   if (g.n == 0) return G16_OK;
-  {
-    // > 64 KiB of dynamic LDS would need the opt-in; the binning passes stay below 48 KiB by construction.
-    // (The attribute is per device and per kernel; nothing to set here any more.)
-  }
-  int rc = msm_front_end(g, ws, d_scalars, st);
-  if (rc) return rc;
+  return msm_front_end(g, ws, d_scalars, st);
+}
+
+int msm_launch_lanes(const MsmGroup& g, MsmWorkspace* ws, hipStream_t st, hipStream_t st2, hipEvent_t gate1,
+                     hipEvent_t gate2) {
+  if (g.n == 0) return G16_OK;
+  int rc;
   if (ws->lane[1].active) {
     hipStream_t s2 = st2 ? st2 : st;
     if (s2 != st) G16_HIP(hipStreamWaitEvent(s2, ws->ev_sorted, 0));
+    ws->lane[1].gate = gate2;
     // the longer chain first when both share a stream
     if ((rc = msm_launch_lane_g2(g, ws, ws->lane[1], s2))) return rc;
   }
   if (ws->lane[0].active) {
+    ws->lane[0].gate = gate1;
     if ((rc = msm_launch_lane_t<Fq29Ops>(g, ws, ws->lane[0], g.d_bases, st))) return rc;
   }
   return G16_OK;
+}
+
+int msm_launch(const MsmGroup& g, MsmWorkspace* ws, const Fr* d_scalars, hipStream_t st, hipStream_t st2) {
+  int rc = msm_launch_front(g, ws, d_scalars, st);
+  if (rc) return rc;
+  return msm_launch_lanes(g, ws, st, st2, nullptr, nullptr);
+}
+
+hipEvent_t msm_event(MsmWorkspace* ws, int which) {
+  return which == 0 ? ws->ev_sorted : which == 1 ? ws->lane[0].ev0 : ws->lane[0].ev1;
 }
 
 int msm_collect(const MsmGroup& g, MsmWorkspace* ws, MsmResult* out) {
@@ -805,7 +841,10 @@ int msm_collect(const MsmGroup& g, MsmWorkspace* ws, MsmResult* out) {
 }
 
 float msm_last_accum_ms(const MsmWorkspace* ws, int lane) { return ws->lane[lane & 1].last_accum_ms; }
-void msm_set_waves(MsmWorkspace* ws, uint32_t waves_per_simd) { ws->waves_per_simd = waves_per_simd; }
+void msm_set_waves(MsmWorkspace* ws, uint32_t waves_g1, uint32_t waves_g2) {
+  ws->lane[0].waves_per_simd = waves_g1;
+  ws->lane[1].waves_per_simd = waves_g2;
+}
 // which: 0..3 front-end marks (lane ignored), 4/5 accumulate start/end, 6..9 the lane's marks
 float msm_event_offset_ms(MsmWorkspace* ws, hipEvent_t base, int lane, int which) {
   float t = 0.f;

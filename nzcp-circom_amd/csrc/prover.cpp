@@ -541,23 +541,46 @@ static void trace_host(const char* what, const std::chrono::steady_clock::time_p
     fprintf(stderr, "[g16 host] %s enqueued at %.3f ms\n", what,
             std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
 }
-// experiment knob: G16_ACC_WAVES = "wh" digits: wavefronts per SIMD of the persistent accumulate grids (0 = full)
-static uint32_t acc_waves(int which) {
-  static const char* occ_s = getenv("G16_ACC_WAVES");
-  return (occ_s && strlen(occ_s) == 2) ? (uint32_t)(occ_s[which] - '0') : 0u;
+// Scheduling knobs (sweeps; the defaults are the measured optimum):
+//   G16_ACC_WAVES = "abc": wavefronts per SIMD of the persistent accumulate grids of the witness G1 lane, the
+//                   witness G2 lane and the H-MSM (0 = the kernel's full occupancy)
+//   G16_GATE      = "ab":  what the witness G1 / G2 accumulate kernels wait for: 0 nothing, 1 the NTT chain,
+//                   2 the H-MSM's sort, 3 the start of the H accumulate, 4 its end
+static uint32_t sched_digit(const char* name, int which, int len, uint32_t dflt) {
+  const char* e = getenv(name);
+  if (!e || (int)strlen(e) != len || e[which] < '0' || e[which] > '9') return dflt;
+  return (uint32_t)(e[which] - '0');
 }
-// witness group (+ the solo B2 group of a malformed key) on its own streams, after c.ev[2]
-static int launch_witness(g16_prover* P, ProofCtx& c, const Fr* d_w) {
+// witness group (+ the solo B2 group of a malformed key): front end on its own stream, after c.ev[2]
+static int launch_witness_front(g16_prover* P, ProofCtx& c, const Fr* d_w) {
   int rc;
   if (c.wst != c.st) G16_HIP(hipStreamWaitEvent(c.wst, c.ev[2], 0));
-  for (int gi : {0, 2}) {
-    if (gi == 2 && !P->b2_solo) continue;
-    msm_set_waves(c.ws[gi], acc_waves(0));
-    hipStream_t s1 = gi == 0 ? c.wst : c.wst2;
-    if (gi == 2 && c.wst2 != c.st) G16_HIP(hipStreamWaitEvent(c.wst2, c.ev[2], 0));
-    G16_HIP(hipEventRecord(c.mev[gi][0], s1));
-    if ((rc = msm_launch(P->grp[gi], c.ws[gi], d_w, s1, gi == 0 ? c.wst2 : s1))) return rc;
-    G16_HIP(hipEventRecord(c.mev[gi][1], s1));
+  G16_HIP(hipEventRecord(c.mev[0][0], c.wst));
+  if ((rc = msm_launch_front(P->grp[0], c.ws[0], d_w, c.wst))) return rc;
+  if (P->b2_solo) {
+    if (c.wst2 != c.st) G16_HIP(hipStreamWaitEvent(c.wst2, c.ev[2], 0));
+    G16_HIP(hipEventRecord(c.mev[2][0], c.wst2));
+    if ((rc = msm_launch_front(P->grp[2], c.ws[2], d_w, c.wst2))) return rc;
+  }
+  return G16_OK;
+}
+// ... and its lanes (accumulate, combine, reduce); `h_launched`: the H-MSM of this proof is already enqueued, so
+// its events may gate the witness accumulates
+static int launch_witness_lanes(g16_prover* P, ProofCtx& c, bool h_launched) {
+  int rc;
+  hipEvent_t gates[2] = {nullptr, nullptr};
+  for (int l = 0; l < 2; l++) {
+    const uint32_t gsel = sched_digit("G16_GATE", l, 2, 0);
+    if (gsel == 1) gates[l] = c.ev[4];
+    else if (gsel >= 2 && gsel <= 4 && h_launched && P->grp[1].n) gates[l] = msm_event(c.ws[1], (int)gsel - 2);
+  }
+  msm_set_waves(c.ws[0], sched_digit("G16_ACC_WAVES", 0, 3, 0), sched_digit("G16_ACC_WAVES", 1, 3, 0));
+  if ((rc = msm_launch_lanes(P->grp[0], c.ws[0], c.wst, c.wst2, gates[0], gates[1]))) return rc;
+  G16_HIP(hipEventRecord(c.mev[0][1], c.wst));
+  if (P->b2_solo) {
+    msm_set_waves(c.ws[2], 0, sched_digit("G16_ACC_WAVES", 1, 3, 0));
+    if ((rc = msm_launch_lanes(P->grp[2], c.ws[2], c.wst2, c.wst2, nullptr, gates[1]))) return rc;
+    G16_HIP(hipEventRecord(c.mev[2][1], c.wst2));
   }
   return G16_OK;
 }
@@ -583,7 +606,7 @@ static int launch_join_h(g16_prover* P, ProofCtx& c, uint32_t lo, uint32_t hi) {
   int rc;
   if (hi > lo && (rc = ntt_join_abc(c.d_a + lo, c.d_b + lo, c.d_c + lo, c.d_p + lo, hi - lo, c.st))) return rc;
   G16_HIP(hipEventRecord(c.ev[4], c.st));
-  msm_set_waves(c.ws[1], acc_waves(1));
+  msm_set_waves(c.ws[1], sched_digit("G16_ACC_WAVES", 2, 3, 0), 0);
   G16_HIP(hipEventRecord(c.mev[1][0], c.st));
   if ((rc = msm_launch(P->grp[1], c.ws[1], c.d_p, c.st, c.st))) return rc;
   G16_HIP(hipEventRecord(c.mev[1][1], c.st));
@@ -597,13 +620,15 @@ static int launch_ctx(g16_prover* P, ProofCtx& c, const Fr* d_w) {
   // critical chain first (host launch order matters: the witness group's ~35 launches cost host time)
   if ((rc = launch_qap_ntt(P, c, d_w, 7u))) return rc;
   trace_host("qap+ntt", th0);
-  if ((rc = launch_witness(P, c, d_w))) return rc;
-  trace_host("witness msm", th0);
+  if ((rc = launch_witness_front(P, c, d_w))) return rc;
+  trace_host("witness front end", th0);
   // a sharded handle joins only the slice of the domain its H bases cover
   uint32_t lo, hi;
   shard_range(P->N, P->shard_rank, P->shard_count, lo, hi);
   if ((rc = launch_join_h(P, c, lo, hi))) return rc;
   trace_host("h msm", th0);
+  if ((rc = launch_witness_lanes(P, c, true))) return rc;
+  trace_host("witness lanes", th0);
   return G16_OK;
 }
 
@@ -747,7 +772,8 @@ int g16_shard_begin(g16_prover* p, uint32_t slot, uint32_t vec_mask, void* const
   } else {
     G16_HIP(hipEventRecord(c.ev[3], c.st));
   }
-  if ((rc = launch_witness(p, c, p->slot_dev[slot]))) return rc;   // keeps running behind the exchange
+  if ((rc = launch_witness_front(p, c, p->slot_dev[slot]))) return rc;   // keeps running behind the exchange
+  if ((rc = launch_witness_lanes(p, c, false))) return rc;
   const F29* src[3] = {c.d_a, c.d_b, c.d_c};
   for (int v = 0; v < 3; v++)
     if (vec_mask & (1u << v))

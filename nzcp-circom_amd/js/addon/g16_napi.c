@@ -6,7 +6,8 @@
  * pin /root/reference/yarn.lock:408-416), so create/prove run in napi async work and return
  * Promises; nothing keeps the loop alive after the Promise settles (Threading).
  *
- * Exports:  create(zkey: Buffer, opts: {device, shardRank, shardCount, windowBits, taskLen}) -> Promise<handle>
+ * Exports:  create(zkey: Buffer, opts: {device, devices: [..], windowBits, taskLen}) -> Promise<handle>
+ *             (devices with more than one entry: ONE proof sharded over those GPUs, g16_multi_* -- BASELINE config 4)
  *           prove(handle, wtns: Buffer, r: Buffer|null, s: Buffer|null) -> Promise<{proof: Buffer(256), pub: Buffer}>
  *           proveBatch(handle, wtns: Buffer[], rs: Buffer|null) -> Promise<[{proof, pub}]>
  *           info(handle) -> {nVars, nPublic, domainSize, nCoefs}
@@ -32,14 +33,22 @@
  * the native prover (its mutex, streams, HBM buffers) is released when the last job retires -- never under a
  * worker thread that still dereferences it. */
 typedef struct {
-  g16_prover* p;
+  g16_prover* p;   /* one GPU ... */
+  g16_multi* m;    /* ... or one proof sharded over several (exactly one of the two is set) */
   uint32_t inflight;
   int closing;
 } handle_t;
 
+static int handle_live(const handle_t* h) { return h && (h->p || h->m); }
+static int handle_info(const handle_t* h, g16_info* inf) {
+  return h->m ? g16_multi_get_info(h->m, inf, NULL) : g16_get_info(h->p, inf);
+}
+
 static void handle_release(handle_t* h) {
   if (h->p) g16_destroy(h->p);
+  if (h->m) g16_multi_destroy(h->m);
   h->p = NULL;
+  h->m = NULL;
 }
 
 static void handle_finalize(napi_env env, void* data, void* hint) {
@@ -55,6 +64,7 @@ typedef struct {
   int nrefs;
   /* create */
   const uint8_t* zkey; size_t zkey_len; g16_opts opts; g16_prover* created;
+  int32_t devices[64]; uint32_t ndev; g16_multi* created_multi;
   /* prove */
   handle_t* h; const uint8_t* wtns; size_t wtns_len; int have_r, have_s; uint8_t r[32], s[32];
   g16_proof proof; uint8_t* pub; size_t pub_len;
@@ -68,12 +78,17 @@ typedef struct {
 static void job_execute(napi_env env, void* data) {
   job_t* j = (job_t*)data;
   if (j->is_create == 1) {
-    j->rc = g16_create(j->zkey, j->zkey_len, &j->opts, &j->created);
+    if (j->ndev > 1) j->rc = g16_multi_create(j->zkey, j->zkey_len, j->devices, j->ndev, &j->opts, &j->created_multi);
+    else j->rc = g16_create(j->zkey, j->zkey_len, &j->opts, &j->created);
   } else if (j->is_create == 2) {
     j->rc = g16_prove_batch(j->h->p, j->bw, j->blen, j->bcount, j->brs, j->bproofs, j->bpub);
   } else {
-    j->rc = g16_prove(j->h->p, j->wtns, j->wtns_len, j->have_r ? j->r : NULL, j->have_s ? j->s : NULL,
-                      &j->proof, j->pub);
+    if (j->h->m)
+      j->rc = g16_multi_prove(j->h->m, j->wtns, j->wtns_len, j->have_r ? j->r : NULL, j->have_s ? j->s : NULL,
+                              &j->proof, j->pub);
+    else
+      j->rc = g16_prove(j->h->p, j->wtns, j->wtns_len, j->have_r ? j->r : NULL, j->have_s ? j->s : NULL,
+                        &j->proof, j->pub);
   }
   if (j->rc) {
     strncpy(j->err, g16_last_error(), sizeof(j->err) - 1);   /* thread-local: read on the worker */
@@ -105,6 +120,7 @@ static void job_complete(napi_env env, napi_status status, void* data) {
   } else if (j->is_create == 1) {
     handle_t* h = (handle_t*)calloc(1, sizeof(handle_t));
     h->p = j->created;
+    h->m = j->created_multi;
     napi_create_external(env, h, handle_finalize, NULL, &result);
     napi_resolve_deferred(env, j->deferred, result);
   } else {
@@ -168,10 +184,29 @@ static napi_value js_create(napi_env env, napi_callback_info info) {
     napi_valuetype t;
     if (napi_typeof(env, argv[1], &t) == napi_ok && t == napi_object) {
       j->opts.device = get_i32(env, argv[1], "device", 0);
-      j->opts.shard_rank = get_i32(env, argv[1], "shardRank", 0);
-      j->opts.shard_count = get_i32(env, argv[1], "shardCount", 1);
       j->opts.window_bits = get_i32(env, argv[1], "windowBits", 0);
       j->opts.task_len = get_i32(env, argv[1], "taskLen", 0);
+      /* devices: [ordinal, ...] -> one shard of the key per entry; a single entry is the plain one-GPU handle */
+      napi_value dv;
+      bool has = false, isarr = false;
+      if (napi_has_named_property(env, argv[1], "devices", &has) == napi_ok && has &&
+          napi_get_named_property(env, argv[1], "devices", &dv) == napi_ok && napi_is_array(env, dv, &isarr) == napi_ok && isarr) {
+        uint32_t n = 0;
+        napi_get_array_length(env, dv, &n);
+        if (n > 64) { free(j); napi_throw_range_error(env, NULL, "devices: at most 64 entries"); return NULL; }
+        for (uint32_t i = 0; i < n; i++) {
+          napi_value el;
+          int32_t d = 0;
+          if (napi_get_element(env, dv, i, &el) != napi_ok || napi_get_value_int32(env, el, &d) != napi_ok) {
+            free(j);
+            napi_throw_type_error(env, NULL, "devices: array of integers expected");
+            return NULL;
+          }
+          j->devices[i] = d;
+        }
+        j->ndev = n;
+        if (n == 1) j->opts.device = j->devices[0];
+      }
     }
   }
   return queue_job(env, j, "g16_create");
@@ -183,7 +218,7 @@ static napi_value js_prove(napi_env env, napi_callback_info info) {
   NAPI_OK(napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
   handle_t* h = NULL;
   bool isbuf = false;
-  if (argc < 2 || napi_get_value_external(env, argv[0], (void**)&h) != napi_ok || !h || !h->p || h->closing ||
+  if (argc < 2 || napi_get_value_external(env, argv[0], (void**)&h) != napi_ok || !handle_live(h) || h->closing ||
       napi_is_buffer(env, argv[1], &isbuf) != napi_ok || !isbuf) {
     napi_throw_type_error(env, NULL, "prove(handle, wtns: Buffer, r, s): bad arguments or handle already destroyed");
     return NULL;
@@ -205,7 +240,7 @@ static napi_value js_prove(napi_env env, napi_callback_info info) {
     }
   }
   g16_info inf;
-  g16_get_info(h->p, &inf);
+  handle_info(h, &inf);
   j->pub_len = (size_t)inf.n_public * 32;
   j->pub = (uint8_t*)malloc(j->pub_len ? j->pub_len : 1);
   h->inflight++;
@@ -223,7 +258,8 @@ static napi_value js_prove_batch(napi_env env, napi_callback_info info) {
   uint32_t n = 0;
   if (argc < 2 || napi_get_value_external(env, argv[0], (void**)&h) != napi_ok || !h || !h->p || h->closing ||
       napi_is_array(env, argv[1], &isarr) != napi_ok || !isarr || napi_get_array_length(env, argv[1], &n) != napi_ok || n == 0) {
-    napi_throw_type_error(env, NULL, "proveBatch(handle, wtns: Buffer[], rs)");
+    napi_throw_type_error(env, NULL, "proveBatch(handle, wtns: Buffer[], rs): bad arguments, destroyed handle, or a "
+                                     "multi-device handle (batches run on one-GPU handles: replicas, SURVEY 8e)");
     return NULL;
   }
   job_t* j = (job_t*)calloc(1, sizeof(job_t));
@@ -266,12 +302,12 @@ static napi_value js_info(napi_env env, napi_callback_info info) {
   napi_value argv[1], out, v;
   handle_t* h = NULL;
   NAPI_OK(napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
-  if (argc < 1 || napi_get_value_external(env, argv[0], (void**)&h) != napi_ok || !h || !h->p) {
+  if (argc < 1 || napi_get_value_external(env, argv[0], (void**)&h) != napi_ok || !handle_live(h)) {
     napi_throw_type_error(env, NULL, "info(handle)");
     return NULL;
   }
   g16_info inf;
-  g16_get_info(h->p, &inf);
+  handle_info(h, &inf);
   NAPI_OK(napi_create_object(env, &out));
   const char* keys[4] = {"nVars", "nPublic", "domainSize", "nCoefs"};
   uint32_t vals[4] = {inf.n_vars, inf.n_public, inf.domain_size, inf.n_coefs};
@@ -308,7 +344,7 @@ static napi_value js_destroy(napi_env env, napi_callback_info info) {
   napi_value argv[1];
   handle_t* h = NULL;
   NAPI_OK(napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
-  if (argc >= 1 && napi_get_value_external(env, argv[0], (void**)&h) == napi_ok && h && h->p) {
+  if (argc >= 1 && napi_get_value_external(env, argv[0], (void**)&h) == napi_ok && handle_live(h)) {
     h->closing = 1;                       /* no new jobs; info()/timings() stay valid until the release */
     if (h->inflight == 0) handle_release(h);
   }

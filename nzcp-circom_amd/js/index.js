@@ -8,8 +8,10 @@
 // proof / publicSignals have exactly snarkjs's shape (decimal strings; key order pi_a, pi_b, pi_c,
 // protocol, curve), so JSON.stringify(x, null, 1) reproduces proof.json / public.json byte for byte
 // given the same blinding (r, s).  Errors are thrown Errors with snarkjs's messages.
-// Extensions (not in snarkjs): opts = {r, s, device, windowBits}; groth16.createProver() keeps the
-// proving key resident in HBM across proofs; prover.proveBatch(wtnsList).
+// Extensions (not in snarkjs): opts = {r, s, device, devices, windowBits}; groth16.createProver() keeps the
+// proving key resident in HBM across proofs; prover.proveBatch(wtnsList); createProver(zkey, {devices: [0, 1, ...]})
+// shards ONE proof over several GPUs of the node (BASELINE config 4: MSM point ranges + the A/B/C evaluation split
+// across the devices, partial sums added on the host).
 "use strict";
 const fs = require("fs");
 const path = require("path");
@@ -112,10 +114,12 @@ class Prover {
 
 async function createProver(zkey, opts = {}) {
   const z = toBuffer(zkey, "zkey");
-  const h = await native().create(z, {
-    device: opts.device | 0, shardRank: opts.shardRank | 0, shardCount: opts.shardCount || 1,
-    windowBits: opts.windowBits | 0, taskLen: opts.taskLen | 0,
-  });
+  if (opts.shardCount > 1 || opts.shardRank)
+    throw new Error("createProver: shardRank/shardCount belong to the C ABI of multi-process hosts; in Node pass " +
+                    "devices: [ordinal, ...] and the proof is sharded over those GPUs inside this process");
+  const nopts = { device: opts.device | 0, windowBits: opts.windowBits | 0, taskLen: opts.taskLen | 0 };
+  if (Array.isArray(opts.devices) && opts.devices.length) nopts.devices = opts.devices.map((d) => d | 0);
+  const h = await native().create(z, nopts);
   return new Prover(h);
 }
 

@@ -1,4 +1,5 @@
-"""N > 1 path on CPU: world_size-2 `gloo` run of the exchange bench.py does on RCCL.
+"""N > 1 path on CPU: world_size-2 `gloo` run of the exchanges bench.py does on RCCL (the 768-byte partial-sum
+all-gather, and -- split_abc -- the scatter of the A/B/C coset-evaluation slices of the sharded H pipeline).
 Each rank owns the point range g16_shard_range gives it, computes its five partial MSM sums (here
 with the Python oracle, since there is no GPU), packs the 768-byte partial blob of the C ABI, the
 blobs are all-gathered, and every rank assembles the proof with the product's host-only
@@ -36,7 +37,7 @@ def _xyzz_blob(P, g2=False):
     return f.g1_to_lem(P) + one + one
 
 
-def _worker(rank, world, port, name, q):
+def _worker(rank, world, port, name, q, split_abc=False):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import __graft_entry__ as entry
@@ -50,7 +51,40 @@ def _worker(rank, world, port, name, q):
     zk = f.read_zkey(zkb)
     w = f.read_wtns(open(golden_path(name + ".wtns"), "rb").read())["w"]
     n, p, N = zk["nVars"], zk["nPublic"], zk["domainSize"]
-    Pv = g.h_scalars(zk, w)
+    if not split_abc:
+        Pv = g.h_scalars(zk, w)          # every rank repeats QAP + 6 NTTs (round-1 scheme)
+    else:
+        # Sharded H pipeline (g16_shard_begin / g16_shard_end, bench.py step()): rank v mod world evaluates vector v
+        # of (A, B, C) on the odd coset, ONE scatter per vector hands rank k its slice [lo_k, hi_k) (equal-size
+        # chunks, padded), rank k joins P = A.B - C only there.  Elements travel as 32-byte LE words here (the
+        # product ships its 40-byte lazy image; the plan -- owners, ranges, padding -- is the same code).
+        from bn254 import R, fr_root
+        lohi = [amd.shard_range(N, k, world) for k in range(world)]
+        pad = max(h - l for l, h in lohi)
+        power = N.bit_length() - 1
+        inc = fr_root(power + 1)
+        evs = g.build_abc(zk, w)
+        mine = []
+        for v in range(3):
+            owner = amd.shard_vector_owner(v, world)
+            recv = torch.zeros(max(1, pad) * 32, dtype=torch.uint8)
+            chunks = None
+            if rank == owner:
+                coef = g.ntt(evs[v], inverse=True)
+                sh, t = [], 1
+                for x in coef:
+                    sh.append(x * t % R)
+                    t = t * inc % R
+                full = g.ntt(sh) + [0] * pad
+                chunks = [torch.frombuffer(bytearray(b"".join(f.le(x) for x in full[l:l + max(1, pad)])), dtype=torch.uint8)
+                          for l, _ in lohi]
+            dist.scatter(recv, chunks, src=owner)
+            raw = recv.numpy().tobytes()
+            mine.append([int.from_bytes(raw[i * 32:(i + 1) * 32], "little") for i in range(pad)])
+        lo, hi = lohi[rank]
+        Pv = [0] * N
+        for i in range(lo, hi):
+            Pv[i] = (mine[0][i - lo] * mine[1][i - lo] - mine[2][i - lo]) % R
 
     def part(bases, scalars, total, grp):
         lo, hi = amd.shard_range(total, rank, world)
@@ -70,13 +104,13 @@ def _worker(rank, world, port, name, q):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("name", ["small"])
-def test_sharded_exchange_gloo_world2(amd, name):
+@pytest.mark.parametrize("name,split_abc", [("small", False), ("small", True)])
+def test_sharded_exchange_gloo_world2(amd, name, split_abc):
     world = 2
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, name, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, name, q, split_abc)) for r in range(world)]
     for pr in procs:
         pr.start()
     for pr in procs:

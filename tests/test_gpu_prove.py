@@ -126,6 +126,25 @@ def test_sharded_h_pipeline_equals_single(amd, shards):
         pv.close()
 
 
+@pytest.mark.parametrize("devices", [[0, 0], [0, 0, 0, 0]])
+def test_multi_device_handle_equals_single(amd, devices):
+    """g16_multi_*: one process, one sharded handle per listed device (here all on GPU 0), host threads per shard,
+    slices moved with device copies, partial sums added on the host -- the C ABI under the Node host's
+    createProver(zkey, {devices: [..]})."""
+    zk, wt, meta = _golden("nzcp513")
+    r, s = f.le(int(meta["r"])), f.le(int(meta["s"]))
+    mp = amd.MultiProver(zk, devices)
+    assert mp.n_shards == len(devices)
+    for _ in range(2):
+        proof, pub = mp.prove(wt, r, s)
+        assert proof == meta["proof"] and pub == meta["public"]
+    with pytest.raises(amd.G16Error, match="Invalid witness length"):
+        mp.prove(_golden("tiny")[1], r, s)
+    proof, pub = mp.prove(wt, r, s)        # still usable after a refused witness
+    assert proof == meta["proof"]
+    mp.close()
+
+
 def test_batch_api(amd):
     import ctypes as C
     zk, wt, meta = _golden("tiny")

@@ -129,6 +129,41 @@ def test_close_while_proofs_are_in_flight(addon):
 
 
 @needs_node
+@pytest.mark.gpu
+def test_multi_device_prover_from_node(addon):
+    """BASELINE config 4 from the product host (VERDICT r1 row e'): createProver(zkey, {devices: [..]}) shards ONE
+    proof over the listed GPUs inside the Node process -- here three shards on GPU 0 (a 1-GPU box): MSM point
+    ranges + the A/B/C coset evaluations split over the shards, slices moved by device copies, partial sums added
+    on the host.  The proof bytes equal the single-GPU proof; snarkjs error texts survive the fan-out."""
+    meta = json.load(open(golden_path("nzcp513.json")))
+    script = f"""
+    const {{ groth16 }} = require({json.dumps(JS)});
+    (async () => {{
+      const z = {json.dumps(golden_path('nzcp513.zkey'))}, w = {json.dumps(golden_path('nzcp513.wtns'))};
+      const pv = await groth16.createProver(z, {{devices: [0, 0, 0]}});
+      const a = await pv.prove(w, {{r: "{meta['r']}", s: "{meta['s']}"}});
+      const [b, c] = await Promise.all([pv.prove(w), pv.prove(w)]);
+      let bad = "none", refused = "none";
+      try {{ await pv.prove({json.dumps(golden_path('tiny.wtns'))}); }} catch (e) {{ bad = e.message; }}
+      try {{ await groth16.createProver(z, {{shardCount: 2}}); }} catch (e) {{ refused = e.message; }}
+      const info = pv.info;
+      await pv.close();
+      const two = await groth16.prove(z, w, {{devices: [0, 0], r: "{meta['r']}", s: "{meta['s']}"}});
+      console.log(JSON.stringify({{a, b, c, bad, refused, info, two}}));
+    }})();
+    """
+    r = run_node(script)
+    assert r.returncode == 0, r.stderr
+    out = json.loads(r.stdout)
+    assert out["a"]["proof"] == meta["proof"] and out["a"]["publicSignals"] == meta["public"]
+    assert out["two"]["proof"] == meta["proof"] and out["two"]["publicSignals"] == meta["public"]
+    assert out["b"]["proof"] != out["c"]["proof"] and out["b"]["publicSignals"] == meta["public"]
+    assert "Invalid witness length. Circuit:" in out["bad"]
+    assert "devices" in out["refused"]
+    assert out["info"]["nPublic"] == 513
+
+
+@needs_node
 def test_nzcp_input_builder_example_pass():
     """pass URI -> ToBeSigned / circuit input / expected public signals, pinned by the
     reference's golden data for the MoH example pass (URI = the test input at
