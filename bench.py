@@ -149,8 +149,12 @@ def batch_leg(amd, args, zkey, wtns, prover0, r, s, log):
     The witnesses come from host memory, so this figure INCLUDES the PCIe upload of every witness.
     Reported next to the single-proof `value`, never instead of it."""
     nslots = min(8, max(1, args.batch_proofs))
-    wts = [wtns] + [amd.synth_witness(args.n_vars, args.n_public, args.n_constraints, SEED, SEED + 100 + i)
-                    for i in range(1, nslots)]
+    if getattr(args, "nz", None):   # the real circuit: witnesses of other passes (same constraint system)
+        nz_params, nz_pass = args.nz
+        wts = [wtns] + [amd.nzcp_circuit_setup(nz_params, nz_pass(i), SEED, 0, want_zkey=False)["wtns"] for i in range(1, nslots)]
+    else:
+        wts = [wtns] + [amd.synth_witness(args.n_vars, args.n_public, args.n_constraints, SEED, SEED + 100 + i)
+                        for i in range(1, nslots)]
     total = args.batch_proofs
     lib = amd.load()
     arr = (ctypes.c_char_p * total)(*[wts[i % nslots] for i in range(total)])
@@ -186,6 +190,11 @@ def main():
     ap.add_argument("--n-vars", type=int, default=1_700_000)
     ap.add_argument("--n-constraints", type=int, default=1_700_000)
     ap.add_argument("--n-public", type=int, default=513)
+    ap.add_argument("--circuit", choices=["nzcp_live", "nzcp_example", "synthetic"], default="nzcp_live",
+                    help="workload circuit: the REAL NZCPPubIdentity constraint system built natively with the CBOR search "
+                         "in the circuit (nzcp_live = nzcp_liveTest.circom's parameters on a live-format pass, BASELINE "
+                         "configs 2-4; nzcp_example = nzcp_exampleTest.circom on the MoH example pass, config 1), or the "
+                         "shape-matched synthetic R1CS at --n-vars / --n-constraints (round 1's upper structural estimate)")
     ap.add_argument("--sha256-blocks", type=int, default=0,
                     help="BASELINE config 5 on a REAL constraint system: this many chained SHA-256 compressions "
                          "(163 fill the 2^22 domain) instead of the shape-matched synthetic circuit")
@@ -202,6 +211,7 @@ def main():
                          "(8 distinct ones cycled; every proof is compared with its one-by-one result)")
     args = ap.parse_args()
 
+    args.nz = None
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -242,6 +252,26 @@ def main():
         args.cpu_sample_div = max(args.cpu_sample_div, 1)
         log(f"sha256-chain setup blocks={args.sha256_blocks} nVars={args.n_vars}: {time.time() - t0:.1f}s, "
             f"zkey {len(zkey) / 1e6:.0f} MB")
+    elif args.circuit != "synthetic":
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        import nzcp_pass
+        live = args.circuit == "nzcp_live"
+        nz_params = amd.NZCP_LIVE_PARAMS if live else amd.NZCP_EXAMPLE_PARAMS
+
+        def nz_pass(i):   # distinct passes of the circuit's format (real live passes are private; the example pass is one)
+            names = [("Jack", "Sparrow", "1960-04-16"), ("Anne-Marie", "Te Whare", "1987-11-30"), ("Li", "Wei", "2001-02-03"),
+                     ("Aroha", "Ngata", "1975-07-21"), ("Sione", "Tuilagi", "1990-12-01"), ("Mere", "Hohepa", "1968-03-15"),
+                     ("Tama", "Parata", "1983-09-09"), ("Olivia", "Smith", "1999-05-27")]
+            g_, f_, d_ = names[i % len(names)]
+            return nzcp_pass.to_be_signed(g_, f_, d_, live=live, exp=1951416330 - i)
+        out = amd.nzcp_circuit_setup(nz_params, nz_pass(0), SEED, threads)
+        zkey, wtns, vkey = out["zkey"], out["wtns"], out["vkey"]
+        args.n_public = 513
+        args.n_vars = (len(wtns) - 76) // 32
+        args.n_constraints = out["n_constraints"]
+        args.nz = (nz_params, nz_pass)
+        log(f"{args.circuit}: NZCPPubIdentity{tuple(nz_params)} built natively with the CBOR search in the circuit: "
+            f"{args.n_constraints} constraints, {args.n_vars} wires; setup {time.time() - t0:.1f}s, zkey {len(zkey) / 1e6:.0f} MB")
     else:
         zkey, wtns, vkey = amd.synth_setup(args.n_vars, args.n_public, args.n_constraints, SEED, threads)
         log(f"synthetic setup nVars={args.n_vars} nConstraints={args.n_constraints}: {time.time() - t0:.1f}s, "
@@ -310,10 +340,13 @@ def main():
     for _ in range(args.warmup):
         step()
     acc = {"qap_ms": 0.0, "ntt_ms": 0.0, "total_ms": 0.0, "msm_ms": [0.0] * 5, "accum": [0.0] * 5}
+    step_ms = []
     fence()
     t0 = time.perf_counter()
     for _ in range(args.steps):
+        ts = time.perf_counter()
         step()
+        step_ms.append(1e3 * (time.perf_counter() - ts))
         tm = prover.timings()
         for k in ("qap_ms", "ntt_ms", "total_ms"):
             acc[k] += tm[k]
@@ -369,15 +402,35 @@ def main():
         bytes_per_launch = sum(96.0 * n for n, _ in launches) / max(1, len(launches))
         ms_per_launch = sum(ms for _, ms in launches) / max(1, len(launches))
         achieved = bytes_per_launch / (ms_per_launch * 1e-3) / 1e9 if ms_per_launch > 0 else 0.0
-        # HBM traffic of that kernel from the PMC passes committed under profiles/ (bench.py cannot
-        # collect counters itself); null when the file is missing or the workload differs
-        traffic, traffic_note = None, "no PMC summary for this workload"
+        # HBM traffic of that kernel from the PMC passes committed under profiles/ (bench.py cannot collect counters
+        # itself).  The summary records the hash of the kernel sources and the workload it was taken on: anything
+        # else -- a kernel edited since, another circuit -- reports null with the reason instead of a stale figure.
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        import kernel_costs
+        src_hash = kernel_costs.kernel_source_hash()
+        workload_id = (f"sha256x{args.sha256_blocks}" if args.sha256_blocks > 0 else
+                       f"{args.circuit}:{args.n_vars}:{args.n_constraints}")
+        traffic, traffic_note = None, "no PMC summary (profiles/r02_pmc_traffic.json) for this build and workload"
         try:
-            pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
-            if world == 1 and args.n_vars == 1_700_000 and args.n_constraints == 1_700_000:
+            pm = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")))
+            if world != 1:
+                traffic_note = "PMC summary is a 1-GPU profile"
+            elif pm.get("kernel_src_sha256") != src_hash:
+                traffic_note = "stale: profiles/r02_pmc_traffic.json was taken on other kernel sources (re-run tools/profile_round.sh)"
+            elif pm.get("workload_id") != workload_id:
+                traffic_note = f"profiles/r02_pmc_traffic.json was taken on workload {pm.get('workload_id')}, not {workload_id}"
+            else:
                 traffic = pm["avg_traffic_bytes_per_launch"]
-                traffic_note = ("rocprofv3 FETCH_SIZE + WRITE_SIZE per launch, profiles/r01_pmc_traffic.json "
+                traffic_note = ("rocprofv3 FETCH_SIZE + WRITE_SIZE per launch, profiles/r02_pmc_traffic.json "
                                 "(separate --pmc passes, raw counters: see its 'method')")
+        except Exception:
+            pass
+        # static instruction counts of the accumulate kernel, generated at build time from the compiler's assembly
+        costs = None
+        try:
+            costs = json.load(open(os.path.join(ROOT, "nzcp-circom_amd", "lib", "kernel_costs.json")))
+            if costs.get("kernel_src_sha256") != src_hash:
+                costs = None
         except Exception:
             pass
         nn, N, k = info.n_vars, info.domain_size, info.n_coefs
@@ -385,15 +438,24 @@ def main():
         out = {
             "metric": "groth16_proofs_per_sec_nzcp_live", "value": round(value, 4), "unit": "proofs/s",
             "n_gpus": world, "steps": K, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / K, 3),
+            "ms_per_step_p50_min": [round(sorted(step_ms)[len(step_ms) // 2], 3), round(min(step_ms), 3)],
             "higher_is_better": True, "scaling": "strong" if (sharded or world == 1) else "weak",
             "vs_baseline": None, "dtype": "u32x8 (256-bit Montgomery integers)",
             "data": ("real SHA-256-chain constraint system built natively (g16_sha256_chain_setup) + trapdoor zkey"
                      if args.sha256_blocks > 0 else
+                     ("real NZCPPubIdentity constraint system (CBOR search + 2 variable-length SHA-256 in the circuit) built "
+                      "natively from the reference's templates (circom itself is not runnable offline), synthetic "
+                      + ("live-format pass" if args.circuit == "nzcp_live" else "example-format pass") + ", trapdoor zkey")
+                     if args.circuit != "synthetic" else
                      "synthetic (shape-matched nzcp_live R1CS + trapdoor zkey; real circuit not buildable offline)"),
             "config": {"workload": (f"sha256 chain, {args.sha256_blocks} compressions (BASELINE config 5), single proof: "
                                     f"nVars={nn}, nPublic={info.n_public}, domain=2^{N.bit_length() - 1}, nCoefs={k}"
                                     if args.sha256_blocks > 0 else
-                                    f"nzcp_live-shaped single proof: nVars={nn}, nConstraints={args.n_constraints}, "
+                                    (f"{args.circuit}Test.circom = NZCPPubIdentity{tuple(args.nz[0])}, single proof: "
+                                     f"nVars={nn}, nConstraints={args.n_constraints}, nPublic={info.n_public}, "
+                                     f"domain=2^{N.bit_length() - 1}, nCoefs={k}")
+                                    if args.circuit != "synthetic" else
+                                    f"nzcp_live-shaped synthetic single proof: nVars={nn}, nConstraints={args.n_constraints}, "
                                     f"nPublic={info.n_public}, domain=2^{N.bit_length() - 1}, nCoefs={k}"),
                        "parallelism": ("1gpu" if world == 1 else
                                        (f"msm-point-range-shard{world}+abc-vector-split+scatter+allgather" if sharded
@@ -410,13 +472,20 @@ def main():
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_note": traffic_note,
                          "algorithmic_bytes_per_launch": round(bytes_per_launch),
                          "avg_launch_ms": round(ms_per_launch, 4),
-                         "int_roofline": {
+                         "int_roofline": ({
                              "kernel": "H-MSM accumulate launch (uniform 254-bit scalars)",
-                             "achieved_Tmad_per_s": round(info.n_h * 16 * 1470 / max(1e-9, acc["accum"][4] / K * 1e-3) / 1e12, 3),
+                             "additions_per_point": -(-255 // info.window_bits[4]),
+                             "mads_per_addition": costs["static_v_mad_u64_u32"],
+                             "valu_per_addition": costs["static_valu"],
+                             "achieved_Tmad_per_s": round(info.n_h * (-(-255 // info.window_bits[4])) * costs["static_v_mad_u64_u32"]
+                                                          / max(1e-9, acc["accum"][4] / K * 1e-3) / 1e12, 3),
                              "peak_Tmad_per_s": 28.6,
-                             "note": "v_mad_u64_u32 count = points x 16 window digits x ~1470 mads per mixed addition (8 products + 2 squarings of 9x29-bit limbs, two of them sharing a reduction); "
-                                     "peak = 256 CU x 4 SIMD x 64 lanes x 2.4 GHz / 5.5 cycles (tools/microbench.hip)"},
-                         "note": "integer-VALU bound: ~2.25k VALU instructions (1.47k v_mad_u64_u32) per mixed addition at ~5.1 cycles each, 16 additions per 96-byte point; see DESIGN.md 3.3"},
+                             "note": "v_mad_u64_u32 count = points x window digits (full window precomputation: ceil(255/c) "
+                                     "additions per point, c = window bits) x the kernel's static mad count per loop iteration "
+                                     "(lib/kernel_costs.json, generated at build time from the compiler's gfx950 assembly); "
+                                     "peak = 256 CU x 4 SIMD x 64 lanes x 2.4 GHz / 5.5 cycles (tools/microbench.hip)"}
+                                          if costs else {"note": "lib/kernel_costs.json missing or generated from other sources: run make"}),
+                         "note": "integer-VALU bound: ~2.2k VALU instructions (1.47k v_mad_u64_u32) per mixed addition at ~5 cycles each, 13 (H, c = 20, precomputed windows) to 20 (witness, c = 13) additions per 96-byte point; see DESIGN.md 3.3"},
         }
         if batch is not None:
             out["batch_throughput"] = batch

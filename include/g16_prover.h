@@ -232,6 +232,23 @@ int g16_nzcp_fixed_layout_setup(const uint8_t* tbs, uint32_t len, const uint32_t
                                 uint32_t exp_off, uint64_t seed, int threads,
                                 uint8_t** zkey, size_t* zkey_len, uint8_t** wtns, size_t* wtns_len,
                                 uint8_t** vkey, size_t* vkey_len, uint8_t** r1cs, size_t* r1cs_len);
+/* Test-only: the NZCP circuit library as native R1CS gadgets (csrc/nzcp_gadgets.h), the twins of the reference's
+ * per-template test circuits /root/reference/circuits/ *_test.circom.  Builds ONE template over the given private
+ * inputs, checks every emitted row on the computed witness and returns the template's output signals (in the
+ * order the reference declares them).  name: getType getX quinSelector getV decodeUint23 decodeUint readType
+ * skipValueScalar skipValue stringEquals readStringLength readMapLength copyString findVCAndExp findCredSubj
+ * readCredSubj concatCredSubj sha256Var; params / inputs: the template parameters / input signals in declaration
+ * order (arrays flattened).  G16_E_STATE with "constraint not satisfied: ..." where circom's witness generator
+ * would throw.  *nout: capacity in, count out. */
+int g16_nzcp_gadget(const char* name, const uint32_t* params, uint32_t nparams, const uint64_t* inputs, uint32_t nin,
+                    uint64_t* outputs, uint32_t* nout, uint32_t* n_constraints);
+/* Test-only: NZCPPubIdentity(params[0..6]) (/root/reference/circuits/nzcptpl.circom:433) with the CBOR search in
+ * the circuit -- nzcp_exampleTest.circom = {0, 314, 0, 4, 2, 4, 5}, nzcp_liveTest.circom = {1, 355, 0, 4, 2, 4, 6} --
+ * built natively for the given ToBeSigned bytes: R1CS, witness, trapdoor key.  Public signals as
+ * /root/reference/test/nzcp.js:41-47.  Any output pair may be NULL. */
+int g16_nzcp_circuit_setup(const uint32_t params[7], const uint8_t* tbs, uint32_t len, uint64_t seed, int threads,
+                           uint8_t** zkey, size_t* zkey_len, uint8_t** wtns, size_t* wtns_len, uint8_t** vkey,
+                           size_t* vkey_len, uint8_t** r1cs, size_t* r1cs_len, uint32_t* n_constraints);
 void g16_free(void* p);
 
 #ifdef __cplusplus

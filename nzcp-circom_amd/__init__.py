@@ -57,7 +57,8 @@ EXPORTS = ["g16_create", "g16_prove", "g16_prove_batch", "g16_stage_witness", "g
            "g16_synth_witness", "g16_free", "g16_finish_host", "g16_shard_range", "g16_r1cs_setup",
            "g16_sha256_chain_setup", "g16_sha256_message_setup", "g16_nzcp_fixed_layout_setup",
            "g16_f29_op", "g16_x29_op", "g16_qap_eval", "g16_shard_begin", "g16_shard_end",
-           "g16_multi_create", "g16_multi_prove", "g16_multi_get_info", "g16_multi_destroy"]
+           "g16_multi_create", "g16_multi_prove", "g16_multi_get_info", "g16_multi_destroy",
+           "g16_nzcp_gadget", "g16_nzcp_circuit_setup"]
 
 
 def load():
@@ -93,6 +94,10 @@ def load():
     lib.g16_qap_eval.argtypes = [vp, C.c_uint32, C.c_char_p, C.c_char_p, C.c_char_p]
     lib.g16_shard_begin.argtypes = [vp, C.c_uint32, C.c_uint32, C.POINTER(vp)]
     lib.g16_shard_end.argtypes = [vp, C.c_uint32, C.POINTER(vp), C.c_char_p]
+    lib.g16_nzcp_gadget.argtypes = [C.c_char_p, C.POINTER(C.c_uint32), C.c_uint32, C.POINTER(C.c_uint64), C.c_uint32,
+                                    C.POINTER(C.c_uint64), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
+    lib.g16_nzcp_circuit_setup.argtypes = [C.POINTER(C.c_uint32), C.c_char_p, C.c_uint32, C.c_uint64, C.c_int] + \
+        [C.c_void_p] * 8 + [C.POINTER(C.c_uint32)]
     lib.g16_multi_create.argtypes = [C.c_char_p, sz, C.POINTER(C.c_int32), C.c_uint32, C.POINTER(Opts), C.POINTER(vp)]
     lib.g16_multi_prove.argtypes = [vp, C.c_char_p, sz, C.c_char_p, C.c_char_p, C.POINTER(Proof), C.c_char_p]
     lib.g16_multi_get_info.argtypes = [vp, C.POINTER(Info), C.POINTER(C.c_uint32)]
@@ -418,6 +423,39 @@ def nzcp_fixed_layout_setup(tbs, segs, exp_off, seed, threads=0, want_zkey=True,
     _check(lib.g16_nzcp_fixed_layout_setup(tbs, len(tbs), off, ln, exp_off, seed, threads, *args))
     out = [(_take(p_, l_) if w_ else None) for p_, l_, w_ in zip(ptrs, lens, want)]
     return {"zkey": out[0], "wtns": out[1], "vkey": out[2], "r1cs": out[3]}
+
+
+def nzcp_gadget(name, params, inputs, max_out=4096):
+    """One template of the NZCP circuit library built natively over `inputs` (the reference's *_test.circom
+    twins): -> (outputs, n_constraints); raises G16Error where circom's witness generator would throw."""
+    lib = load()
+    prm = (C.c_uint32 * max(1, len(params)))(*params)
+    inp = (C.c_uint64 * max(1, len(inputs)))(*inputs)
+    out = (C.c_uint64 * max_out)()
+    nout, ncons = C.c_uint32(max_out), C.c_uint32()
+    _check(lib.g16_nzcp_gadget(name.encode(), prm, len(params), inp, len(inputs), out, C.byref(nout), C.byref(ncons)))
+    return list(out[:nout.value]), ncons.value
+
+
+NZCP_EXAMPLE_PARAMS = (0, 314, 0, 4, 2, 4, 5)    # /root/reference/circuits/nzcp_exampleTest.circom
+NZCP_LIVE_PARAMS = (1, 355, 0, 4, 2, 4, 6)       # /root/reference/circuits/nzcp_liveTest.circom
+
+
+def nzcp_circuit_setup(params, tbs, seed, threads=0, want_zkey=True, want_r1cs=False):
+    """NZCPPubIdentity(*params) with the CBOR search in the circuit, built natively for the ToBeSigned bytes `tbs`
+    -> dict(zkey, wtns, vkey, r1cs, n_constraints)."""
+    lib = load()
+    ptrs = [C.c_void_p() for _ in range(4)]
+    lens = [C.c_size_t() for _ in range(4)]
+    want = [want_zkey, True, want_zkey, want_r1cs]
+    args = []
+    for p_, l_, w_ in zip(ptrs, lens, want):
+        args += [C.byref(p_) if w_ else None, C.byref(l_) if w_ else None]
+    ncons = C.c_uint32()
+    prm = (C.c_uint32 * 7)(*params)
+    _check(lib.g16_nzcp_circuit_setup(prm, tbs, len(tbs), seed, threads, *args, C.byref(ncons)))
+    out = [(_take(p_, l_) if w_ else None) for p_, l_, w_ in zip(ptrs, lens, want)]
+    return {"zkey": out[0], "wtns": out[1], "vkey": out[2], "r1cs": out[3], "n_constraints": ncons.value}
 
 
 def sha256_message_setup(msg, seed, threads=0, want_zkey=True, want_r1cs=False):

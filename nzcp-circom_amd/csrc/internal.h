@@ -52,6 +52,8 @@ int ntt_coset_scale(const NttTables& t, F29* const* vecs, int nvec, hipStream_t 
 // through the bit-reversal permutation; export can fold in the 1/N of the inverse transform)
 int ntt_import(const NttTables& t, const Fr* in, F29* out, bool bitrev, hipStream_t st);
 int ntt_export(const NttTables& t, const F29* in, Fr* out, bool bitrev, bool scale_ninv, hipStream_t st);
+// ntt_dit_forward of a, b, c with the join fused into the last pass (the vectors are consumed)
+int ntt_dit_forward_join(const NttTables& t, F29* a, F29* b, F29* c, Fr* p_std, hipStream_t st);
 // P[i] = plain(a[i]*b[i] - c[i])   (qap_joinABC + batchFromMontgomery)
 int ntt_join_abc(const F29* a, const F29* b, const F29* c, Fr* p_std, size_t n, hipStream_t st);
 

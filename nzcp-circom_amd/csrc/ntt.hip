@@ -41,30 +41,11 @@ __device__ __forceinline__ uint32_t bitrev_dev(uint32_t x, int bits) {
   return bits == 0 ? 0u : (__brev(x) >> (32 - bits));
 }
 
-// `post` (optional): table multiplied into every element on store (the coset/1-over-N table after the
-// last inverse pass), saving one sweep over the vectors.
-__global__ __launch_bounds__(kThreads) void ntt_pass_kernel(VecPtrs vecs, const F29* __restrict__ tw,
-                                                            int L, int tile_log, int lo_bits, int S,
-                                                            int tb, int dif, const F29* __restrict__ post) {
-  extern __shared__ __align__(16) unsigned char ntt_lds[];
-  F29* tile = reinterpret_cast<F29*>(ntt_lds);
-  F29* __restrict__ x = vecs.p[blockIdx.y];
-  const uint32_t tile_n = 1u << tile_log;
-  const uint32_t T = 1u << tb;
-  const uint32_t t = blockIdx.x;
-  size_t base;
-  if (lo_bits == 0) {
-    base = (size_t)t << tile_log;
-  } else {
-    const uint32_t per = (1u << lo_bits) >> tb;  // lo blocks per hi group
-    const uint32_t lo_blk = t % per, hi = t / per;
-    base = ((size_t)hi << (lo_bits + S)) + (size_t)lo_blk * T;
-  }
-  auto gidx = [&](uint32_t e) -> size_t {
-    return base + ((size_t)(e >> tb) << lo_bits) + (e & (T - 1));
-  };
-  for (uint32_t e = threadIdx.x; e < tile_n; e += kThreads) tile[e] = fr29_weak_reduce(x[gidx(e)]);
-  __syncthreads();
+// The butterfly stages of one pass on a tile staged in LDS (shared by the plain pass kernel and the fused last
+// forward pass).  gidx maps a tile element to its index in the vector.
+template <class GIdx>
+__device__ __forceinline__ void ntt_tile_stages(F29* __restrict__ tile, const F29* __restrict__ tw, const GIdx& gidx,
+                                                uint32_t tile_n, int L, int lo_bits, int S, int tb, int dif) {
   for (int k = 0; k < S; k++) {
     const int st = dif ? (S - 1 - k) : k;
     const int bit = tb + st;
@@ -103,6 +84,33 @@ __global__ __launch_bounds__(kThreads) void ntt_pass_kernel(VecPtrs vecs, const 
       __syncthreads();
     }
   }
+}
+
+// `post` (optional): table multiplied into every element on store (the coset/1-over-N table after the
+// last inverse pass), saving one sweep over the vectors.
+__global__ __launch_bounds__(kThreads) void ntt_pass_kernel(VecPtrs vecs, const F29* __restrict__ tw,
+                                                            int L, int tile_log, int lo_bits, int S,
+                                                            int tb, int dif, const F29* __restrict__ post) {
+  extern __shared__ __align__(16) unsigned char ntt_lds[];
+  F29* tile = reinterpret_cast<F29*>(ntt_lds);
+  F29* __restrict__ x = vecs.p[blockIdx.y];
+  const uint32_t tile_n = 1u << tile_log;
+  const uint32_t T = 1u << tb;
+  const uint32_t t = blockIdx.x;
+  size_t base;
+  if (lo_bits == 0) {
+    base = (size_t)t << tile_log;
+  } else {
+    const uint32_t per = (1u << lo_bits) >> tb;  // lo blocks per hi group
+    const uint32_t lo_blk = t % per, hi = t / per;
+    base = ((size_t)hi << (lo_bits + S)) + (size_t)lo_blk * T;
+  }
+  auto gidx = [&](uint32_t e) -> size_t {
+    return base + ((size_t)(e >> tb) << lo_bits) + (e & (T - 1));
+  };
+  for (uint32_t e = threadIdx.x; e < tile_n; e += kThreads) tile[e] = fr29_weak_reduce(x[gidx(e)]);
+  __syncthreads();
+  ntt_tile_stages(tile, tw, gidx, tile_n, L, lo_bits, S, tb, dif);
   if (post) {
     for (uint32_t e = threadIdx.x; e < tile_n; e += kThreads) {
       const size_t g = gidx(e);
@@ -110,6 +118,50 @@ __global__ __launch_bounds__(kThreads) void ntt_pass_kernel(VecPtrs vecs, const 
     }
   } else {
     for (uint32_t e = threadIdx.x; e < tile_n; e += kThreads) x[gidx(e)] = tile[e];
+  }
+}
+
+// The LAST forward (DIT) pass of the three vectors A, B, C fused with qap_joinABC + batchFromMontgomery: a
+// workgroup runs the pass on the same tile of A, then B, then C (one 20 KiB LDS tile, reused), keeps its own
+// elements in registers and writes only P[g] = plain(A'[g] B'[g] - C'[g]): the three transformed vectors never
+// go back to HBM (2 x 252 MB less traffic at N = 2^21, and the join kernel disappears).
+template <int EPT>   // tile elements per thread = max(1, tile_n / 256)
+__global__ __launch_bounds__(kThreads) void ntt_last_pass_join_kernel(VecPtrs vecs, const F29* __restrict__ tw, int L,
+                                                                      int tile_log, int lo_bits, int S, int tb,
+                                                                      Fr* __restrict__ p_out) {
+  extern __shared__ __align__(16) unsigned char ntt_lds[];
+  F29* tile = reinterpret_cast<F29*>(ntt_lds);
+  const uint32_t tile_n = 1u << tile_log;
+  const uint32_t T = 1u << tb;
+  const uint32_t t = blockIdx.x;
+  size_t base;
+  if (lo_bits == 0) {
+    base = (size_t)t << tile_log;
+  } else {
+    const uint32_t per = (1u << lo_bits) >> tb;
+    const uint32_t lo_blk = t % per, hi = t / per;
+    base = ((size_t)hi << (lo_bits + S)) + (size_t)lo_blk * T;
+  }
+  auto gidx = [&](uint32_t e) -> size_t {
+    return base + ((size_t)(e >> tb) << lo_bits) + (e & (T - 1));
+  };
+  F29 acc[EPT];   // a'[e], then a'[e] b'[e]
+#pragma unroll 1
+  for (int v = 0; v < 3; v++) {
+    const F29* __restrict__ x = vecs.p[v];
+    for (uint32_t e = threadIdx.x; e < tile_n; e += kThreads) tile[e] = fr29_weak_reduce(x[gidx(e)]);
+    __syncthreads();
+    ntt_tile_stages(tile, tw, gidx, tile_n, L, lo_bits, S, tb, 0);
+#pragma unroll
+    for (int k = 0; k < EPT; k++) {
+      const uint32_t e = threadIdx.x + (uint32_t)k * kThreads;
+      if (e < tile_n) {
+        if (v == 0) acc[k] = tile[e];
+        else if (v == 1) acc[k] = fr29_mul(acc[k], tile[e]);
+        else p_out[gidx(e)] = fr29_to_plain(fr29_sub<2>(acc[k], fr29_weak_reduce(tile[e])));
+      }
+    }
+    __syncthreads();
   }
 }
 
@@ -185,6 +237,10 @@ int ntt_tables_create(NttTables& t, int L, hipStream_t st) {
   }
   G16_HIP(hipFuncSetAttribute((const void*)ntt_pass_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                               (int)(sizeof(F29) << kTileLogCap)));
+  G16_HIP(hipFuncSetAttribute((const void*)ntt_last_pass_join_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)(sizeof(F29) << kTileLogCap)));
+  G16_HIP(hipFuncSetAttribute((const void*)ntt_last_pass_join_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)(sizeof(F29) << kTileLogCap)));
   const size_t N = (size_t)1 << L, half = N > 1 ? N / 2 : 1;
   G16_HIP(hipMalloc(&t.tw_fwd, half * sizeof(F29)));
   G16_HIP(hipMalloc(&t.tw_inv, half * sizeof(F29)));
@@ -236,6 +292,33 @@ int ntt_dif_inverse_coset(const NttTables& t, F29* const* vecs, int nvec, hipStr
 }
 int ntt_dit_forward(const NttTables& t, F29* const* vecs, int nvec, hipStream_t st) {
   return run_passes(t, vecs, nvec, false, nullptr, st);
+}
+
+// Forward transform of (a, b, c) with the join fused into the last pass: p_std[i] = plain(a'[i] b'[i] - c'[i]).
+// The vectors are left half-transformed (their last pass is never written back).
+int ntt_dit_forward_join(const NttTables& t, F29* a, F29* b, F29* c, Fr* p_std, hipStream_t st) {
+  if (t.L == 0) return ntt_join_abc(a, b, c, p_std, 1, st);
+  if (t.tile_log > 11) { set_error("ntt: tile too large for the fused join"); return G16_E_ARG; }
+  VecPtrs vp{};
+  vp.p[0] = a; vp.p[1] = b; vp.p[2] = c;
+  const unsigned ntiles = 1u << (t.L - t.tile_log);
+  const int np = (int)t.passes.size();
+  for (int k = 0; k + 1 < np; k++) {
+    const NttPass& p = t.passes[k];
+    ntt_pass_kernel<<<dim3(ntiles, 3), kThreads, sizeof(F29) << t.tile_log, st>>>(vp, t.tw_fwd, t.L, t.tile_log, p.lo_bits,
+                                                                                   p.S, p.tb, 0, nullptr);
+  }
+  const NttPass& p = t.passes[np - 1];
+  const size_t lds = sizeof(F29) << t.tile_log;
+#define G16_JOIN_LAUNCH(EPT) \
+  ntt_last_pass_join_kernel<EPT><<<ntiles, kThreads, lds, st>>>(vp, t.tw_fwd, t.L, t.tile_log, p.lo_bits, p.S, p.tb, p_std)
+  if (t.tile_log <= 8) G16_JOIN_LAUNCH(1);
+  else if (t.tile_log == 9) G16_JOIN_LAUNCH(2);
+  else if (t.tile_log == 10) G16_JOIN_LAUNCH(4);
+  else G16_JOIN_LAUNCH(8);
+#undef G16_JOIN_LAUNCH
+  G16_HIP(hipGetLastError());
+  return G16_OK;
 }
 
 int ntt_coset_scale(const NttTables& t, F29* const* vecs, int nvec, hipStream_t st) {

@@ -314,10 +314,13 @@ static int create_impl(const uint8_t* zkey, size_t len, const g16_opts* opts, g1
   if ((rc = ntt_tables_create(P->ntt, P->L, P->st))) return rc;
   MsmConfig cfg;
   cfg.task_len = opts ? opts->task_len : 0;
-  // tuning overrides: G16_WINDOW_BITS="witness,h" (0 = auto), G16_TASK_LEN=n
-  int c_over[2] = {0, 0};
+  // tuning overrides: G16_WINDOW_BITS="witness,h", G16_TASK_LEN="witness,h" (0 = auto)
+  int c_over[2] = {0, 0}, tl_over[2] = {0, 0};
   if (const char* e = getenv("G16_WINDOW_BITS")) sscanf(e, "%d,%d", &c_over[0], &c_over[1]);
-  if (const char* e = getenv("G16_TASK_LEN")) cfg.task_len = atoi(e);
+  if (const char* e = getenv("G16_TASK_LEN")) {
+    if (sscanf(e, "%d,%d", &tl_over[0], &tl_over[1]) == 1) tl_over[1] = tl_over[0];
+  }
+  const int tl_opt = cfg.task_len;
   {
     // witness group: A over w, B1 (+ its G2 twin B2) over w, C over w[p+1:]; each section's point range sharded
     uint32_t lo[3], hi[3];
@@ -331,6 +334,7 @@ static int create_impl(const uint8_t* zkey, size_t len, const g16_opts* opts, g1
     secs[2].bases_host = sb[3].p + (size_t)lo[2] * 64; secs[2].n_total = hi[2] - lo[2];
     secs[2].scalar_offset = P->nPublic + 1 + lo[2];
     cfg.c = c_over[0] ? c_over[0] : (opts ? opts->window_bits : 0);
+    cfg.task_len = tl_over[0] ? tl_over[0] : tl_opt;
     cfg.dense = false;    // witness scalars are mostly 0/1/small
     cfg.precomp = 1;
     rc = msm_group_create(P->grp[0], secs, 3, cfg);
@@ -351,6 +355,7 @@ static int create_impl(const uint8_t* zkey, size_t len, const g16_opts* opts, g1
     shard_range(P->N, P->shard_rank, P->shard_count, hlo, hhi);
     hsec.bases_host = sb[4].p + (size_t)hlo * 64; hsec.n_total = hhi - hlo; hsec.scalar_offset = hlo;
     cfg.c = c_over[1] ? c_over[1] : (opts ? opts->window_bits : 0);
+    cfg.task_len = tl_over[1] ? tl_over[1] : tl_opt;
     cfg.dense = true;
     cfg.precomp = opts ? (int)((opts->flags >> 8) & 0xffu) : 0;
     if ((rc = msm_group_create(P->grp[1], &hsec, 1, cfg))) return rc;
@@ -570,11 +575,14 @@ static int launch_witness_lanes(g16_prover* P, ProofCtx& c, bool h_launched) {
   int rc;
   hipEvent_t gates[2] = {nullptr, nullptr};
   for (int l = 0; l < 2; l++) {
-    const uint32_t gsel = sched_digit("G16_GATE", l, 2, 0);
+    // default (r02 sweeps, 40-proof medians): the G1 accumulate waits for the NTT chain -- its persistent grid
+    // would otherwise take the CUs from the transforms on the critical chain (8.66 -> 8.1 ms per proof)
+    const uint32_t gsel = sched_digit("G16_GATE", l, 2, l == 0 ? 1u : 0u);
     if (gsel == 1) gates[l] = c.ev[4];
     else if (gsel >= 2 && gsel <= 4 && h_launched && P->grp[1].n) gates[l] = msm_event(c.ws[1], (int)gsel - 2);
   }
-  msm_set_waves(c.ws[0], sched_digit("G16_ACC_WAVES", 0, 3, 0), sched_digit("G16_ACC_WAVES", 1, 3, 0));
+  // ... and runs 3 of its 4 wavefronts per SIMD, which leaves room for the H-MSM's latency-bound front end
+  msm_set_waves(c.ws[0], sched_digit("G16_ACC_WAVES", 0, 3, 3), sched_digit("G16_ACC_WAVES", 1, 3, 0));
   if ((rc = msm_launch_lanes(P->grp[0], c.ws[0], c.wst, c.wst2, gates[0], gates[1]))) return rc;
   G16_HIP(hipEventRecord(c.mev[0][1], c.wst));
   if (P->b2_solo) {
@@ -586,10 +594,15 @@ static int launch_witness_lanes(g16_prover* P, ProofCtx& c, bool h_launched) {
 }
 // QAP evaluation, then the odd-coset evaluation (iNTT, coset shift, NTT) of the vectors in `mask` (bit 0 = A,
 // 1 = B, 2 = C) on the main stream
-static int launch_qap_ntt(g16_prover* P, ProofCtx& c, const Fr* d_w, uint32_t mask) {
+static int launch_qap_ntt(g16_prover* P, ProofCtx& c, const Fr* d_w, uint32_t mask, bool fuse_join = false) {
   int rc;
   if ((rc = qap_eval(P->csr, d_w, c.d_a, c.d_b, c.d_c, c.st))) return rc;
   G16_HIP(hipEventRecord(c.ev[3], c.st));
+  if (fuse_join) {   // all three vectors here: the last forward pass writes P directly
+    F29* v3[3] = {c.d_a, c.d_b, c.d_c};
+    if ((rc = ntt_dif_inverse_coset(P->ntt, v3, 3, c.st))) return rc;
+    return ntt_dit_forward_join(P->ntt, c.d_a, c.d_b, c.d_c, c.d_p, c.st);
+  }
   F29* all[3] = {c.d_a, c.d_b, c.d_c};
   F29* vecs[3];
   int nv = 0;
@@ -602,9 +615,9 @@ static int launch_qap_ntt(g16_prover* P, ProofCtx& c, const Fr* d_w, uint32_t ma
   return G16_OK;
 }
 // P = A'.B' - C' over [lo, hi) of the domain, then the H-MSM of this handle's point range
-static int launch_join_h(g16_prover* P, ProofCtx& c, uint32_t lo, uint32_t hi) {
+static int launch_join_h(g16_prover* P, ProofCtx& c, uint32_t lo, uint32_t hi, bool joined = false) {
   int rc;
-  if (hi > lo && (rc = ntt_join_abc(c.d_a + lo, c.d_b + lo, c.d_c + lo, c.d_p + lo, hi - lo, c.st))) return rc;
+  if (!joined && hi > lo && (rc = ntt_join_abc(c.d_a + lo, c.d_b + lo, c.d_c + lo, c.d_p + lo, hi - lo, c.st))) return rc;
   G16_HIP(hipEventRecord(c.ev[4], c.st));
   msm_set_waves(c.ws[1], sched_digit("G16_ACC_WAVES", 2, 3, 0), 0);
   G16_HIP(hipEventRecord(c.mev[1][0], c.st));
@@ -618,14 +631,15 @@ static int launch_ctx(g16_prover* P, ProofCtx& c, const Fr* d_w) {
   const auto th0 = std::chrono::steady_clock::now();
   G16_HIP(hipEventRecord(c.ev[2], c.st));
   // critical chain first (host launch order matters: the witness group's ~35 launches cost host time)
-  if ((rc = launch_qap_ntt(P, c, d_w, 7u))) return rc;
+  static const bool fuse = !(getenv("G16_NO_FUSED_JOIN") && atoi(getenv("G16_NO_FUSED_JOIN")));
+  if ((rc = launch_qap_ntt(P, c, d_w, 7u, fuse))) return rc;
   trace_host("qap+ntt", th0);
   if ((rc = launch_witness_front(P, c, d_w))) return rc;
   trace_host("witness front end", th0);
   // a sharded handle joins only the slice of the domain its H bases cover
   uint32_t lo, hi;
   shard_range(P->N, P->shard_rank, P->shard_count, lo, hi);
-  if ((rc = launch_join_h(P, c, lo, hi))) return rc;
+  if ((rc = launch_join_h(P, c, lo, hi, fuse))) return rc;
   trace_host("h msm", th0);
   if ((rc = launch_witness_lanes(P, c, true))) return rc;
   trace_host("witness lanes", th0);

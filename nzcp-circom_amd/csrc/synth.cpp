@@ -800,6 +800,26 @@ void build_nzcp_fixed_layout(ShaBuilder& sb, const uint8_t* tbs, uint32_t len, c
   sb.c.m = (uint32_t)sb.c.rowA.size() - 1;
 }
 
+#include "nzcp_gadgets.h"
+
+// every row of the builder's R1CS evaluated on its witness: the index of the first row with <A,w><B,w> != <C,w>,
+// or -1
+int64_t first_unsatisfied_row(const CBuilder& cb) {
+  const Circuit& c = cb.c;
+  const uint32_t m = (uint32_t)c.rowA.size() - 1;
+  auto dot = [&](const std::vector<Term>& t, uint32_t lo, uint32_t hi) {
+    FrM s = fp_zero<FrParams>();
+    for (uint32_t k = lo; k < hi; k++) s = fp_add(s, fp_mul(t[k].cf, cb.wire_val(t[k].s)));
+    return s;
+  };
+  for (uint32_t r = 0; r < m; r++) {
+    const FrM a = dot(c.tA, c.rowA[r], c.rowA[r + 1]), b = dot(c.tB, c.rowB[r], c.rowB[r + 1]);
+    const FrM cc = dot(c.tC, c.rowC[r], c.rowC[r + 1]);
+    if (!CBuilder::fr_eq(fp_mul(a, b), cc)) return (int64_t)r;
+  }
+  return -1;
+}
+
 void write_r1cs(const Circuit& c, uint32_t n_pub_out, uint32_t n_pub_in, Buf& b) {
   const size_t nnz = c.tA.size() + c.tB.size() + c.tC.size();
   const size_t s1 = 4 + 32 + 16 + 8 + 4, s2 = (size_t)c.m * 12 + nnz * 36, s3 = (size_t)c.n * 8;
@@ -885,6 +905,167 @@ extern "C" int g16_nzcp_fixed_layout_setup(const uint8_t* tbs, uint32_t len, con
   ShaBuilder sb;
   build_nzcp_fixed_layout(sb, tbs, len, seg_off, seg_len, exp_off);
   return sha_emit(sb, seed, threads, zkey, zkey_len, wtns, wtns_len, vkey, vkey_len, r1cs, r1cs_len);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// The NZCP circuit library as native gadgets (nzcp_gadgets.h), one template at a time -- the twins of the
+// reference's *_test.circom entry points (/root/reference/circuits/*_test.circom), so that its test vectors
+// (/root/reference/test/cbor.js, quinSelector.js, nzcp.js) can be replayed against the natively built rows.
+namespace g16 {
+namespace {
+using V = CBuilder::V;
+
+int run_gadget(CBuilder& cb, const std::string& name, const uint32_t* prm, uint32_t nprm, const uint64_t* in, uint32_t nin,
+               std::vector<V>& outs) {
+  uint32_t pos_in = 0;
+  auto P = [&](uint32_t i) -> uint32_t { return i < nprm ? prm[i] : 0u; };
+  auto input = [&]() -> V {   // a private input wire
+    const uint64_t v = pos_in < nin ? in[pos_in] : 0;
+    pos_in++;
+    return cb.of_wire(cb.new_wire(v));
+  };
+  auto inputs = [&](uint32_t n) { std::vector<V> r; for (uint32_t i = 0; i < n; i++) r.push_back(input()); return r; };
+  if (name == "getType") { outs = {cb.get_type(input())}; }
+  else if (name == "getX") { outs = {cb.get_x(input())}; }
+  else if (name == "quinSelector") { const std::vector<V> arr = inputs(P(0)); const V idx = input(); outs = {cb.quin_selector(arr, idx)}; }
+  else if (name == "getV") { const std::vector<V> b = inputs(P(0)); const V pos = input(); outs = {cb.get_v(b, pos)}; }
+  else if (name == "decodeUint23") { outs = {cb.decode_uint23(input())}; }
+  else if (name == "decodeUint") {   // inputs: bytes[N], pos, v
+    const std::vector<V> b = inputs(P(0)); const V pos = input(); const V v = input();
+    const CBuilder::UintOut o = cb.decode_uint(b, pos, v);
+    outs = {o.value, o.next_pos};
+  } else if (name == "readType") {
+    const std::vector<V> b = inputs(P(0)); const V pos = input();
+    const CBuilder::TypeOut o = cb.read_type(b, pos);
+    outs = {o.next_pos, o.type, o.v};
+  } else if (name == "skipValueScalar") { const std::vector<V> b = inputs(P(0)); const V pos = input(); outs = {cb.skip_value_scalar(b, pos)}; }
+  else if (name == "skipValue") { const std::vector<V> b = inputs(P(0)); const V pos = input(); outs = {cb.skip_value(b, pos, P(1))}; }
+  else if (name == "stringEquals") {   // params: N, constLen, const bytes...; inputs: bytes[N], pos, len
+    const uint32_t cl = P(1);
+    std::vector<uint8_t> cbts(cl);
+    for (uint32_t i = 0; i < cl; i++) cbts[i] = (uint8_t)P(2 + i);
+    const std::vector<V> b = inputs(P(0)); const V pos = input(); const V len = input();
+    outs = {cb.string_equals(b, pos, len, cbts.data(), cl)};
+  } else if (name == "readStringLength") {
+    const std::vector<V> b = inputs(P(0)); const V pos = input();
+    const CBuilder::LenOut o = cb.read_string_length(b, pos);
+    outs = {o.len, o.next_pos};
+  } else if (name == "readMapLength") {
+    const std::vector<V> b = inputs(P(0)); const V pos = input();
+    const CBuilder::LenOut o = cb.read_map_length(b, pos);
+    outs = {o.len, o.next_pos};
+  } else if (name == "copyString") {
+    const std::vector<V> b = inputs(P(0)); const V pos = input();
+    const CBuilder::CopyOut o = cb.copy_string(b, pos, P(1));
+    outs = o.out; outs.push_back(o.next_pos); outs.push_back(o.len);
+  } else if (name == "findVCAndExp" || name == "findCredSubj") {   // params: N, maxArr, maxMap; inputs: bytes[N], pos, mapLen
+    static const uint8_t kVC[2] = {118, 99};
+    static const uint8_t kCS[17] = {99, 114, 101, 100, 101, 110, 116, 105, 97, 108, 83, 117, 98, 106, 101, 99, 116};
+    const std::vector<V> b = inputs(P(0)); const V pos = input(); const V ml = input();
+    const bool vc = name == "findVCAndExp";
+    const CBuilder::FindOut o = cb.find_in_map(b, pos, ml, P(1), P(2), vc ? kVC : kCS, vc ? 2 : 17, vc);
+    outs = {o.needle_pos};
+    if (vc) outs.push_back(o.exp_pos);
+  } else if (name == "readCredSubj") {   // params: N, maxBufferLen; inputs: bytes[N], pos, mapLen
+    const std::vector<V> b = inputs(P(0)); const V pos = input(); const V ml = input();
+    const CBuilder::CredSubj o = cb.read_cred_subj(b, pos, ml, P(1));
+    outs = o.given; outs.push_back(o.given_len);
+    outs.insert(outs.end(), o.family.begin(), o.family.end()); outs.push_back(o.family_len);
+    outs.insert(outs.end(), o.dob.begin(), o.dob.end()); outs.push_back(o.dob_len);
+  } else if (name == "concatCredSubj") {   // params: maxBufferLen; inputs: given[M], givenLen, family[M], familyLen, dob[M], dobLen
+    CBuilder::CredSubj cs;
+    cs.given = inputs(P(0)); cs.given_len = input();
+    cs.family = inputs(P(0)); cs.family_len = input();
+    cs.dob = inputs(P(0)); cs.dob_len = input();
+    const CBuilder::Concat o = cb.concat_cred_subj(cs, P(0));
+    outs = o.result; outs.push_back(o.result_len);
+  } else if (name == "sha256Var") {   // params: blockSpace; inputs: len_bits, then the message BYTES (bits are derived)
+    const int bs = (int)P(0);
+    const V len = input();
+    std::vector<Bit> bits((size_t)512 << bs, bit_const(0));
+    const uint32_t out_base = cb.new_wire(0);
+    for (int i = 1; i < 256; i++) cb.new_wire(0);
+    for (uint32_t j = 0; j + 1 < nin && j < (64u << bs); j++)
+      for (int i = 0; i < 8; i++) {
+        const uint32_t wire = cb.new_wire((in[1 + j] >> (7 - i)) & 1);
+        cb.boolean(wire);
+        bits[(size_t)j * 8 + (size_t)i] = bit_wire(wire);
+      }
+    cb.sha256_var(bits, len, bs, out_base);
+    for (int i = 0; i < 256; i++) outs.push_back(cb.of_wire(out_base + (uint32_t)i));
+  } else {
+    set_error("unknown gadget: " + name);
+    return G16_E_ARG;
+  }
+  return G16_OK;
+}
+}  // namespace
+}  // namespace g16
+
+// Test-only: build ONE template of the NZCP circuit library over the given private inputs, check every emitted
+// R1CS row on the computed witness and return the template's outputs.  G16_E_STATE + "constraint not satisfied:
+// ..." when the inputs violate one of the template's `===` / Num2Bits range constraints (where circom's witness
+// generator throws).  outputs: *nout in = capacity, out = count.
+extern "C" int g16_nzcp_gadget(const char* name, const uint32_t* params, uint32_t nparams, const uint64_t* inputs,
+                               uint32_t nin, uint64_t* outputs, uint32_t* nout, uint32_t* n_constraints) {
+  if (!name || !nout || (nparams && !params) || (nin && !inputs)) { set_error("NULL argument"); return G16_E_ARG; }
+  CBuilder cb;
+  std::vector<CBuilder::V> outs;
+  int rc = run_gadget(cb, name, params, nparams, inputs, nin, outs);
+  if (rc) return rc;
+  if (n_constraints) *n_constraints = (uint32_t)cb.c.rowA.size() - 1;
+  const int64_t bad = first_unsatisfied_row(cb);
+  if (!cb.ok) {
+    set_error("constraint not satisfied: " + cb.fail);
+    return G16_E_STATE;
+  }
+  if (bad >= 0) { set_error("internal: R1CS row " + std::to_string(bad) + " is not satisfied by the computed witness"); return G16_E_HIP; }
+  if (outs.size() > *nout) { set_error("output buffer too small"); return G16_E_ARG; }
+  for (size_t i = 0; i < outs.size(); i++) {
+    uint64_t v = 0;
+    if (!CBuilder::small_of(outs[i].val, v)) { set_error("gadget output is not a small integer"); return G16_E_STATE; }
+    if (outputs) outputs[i] = v;
+  }
+  *nout = (uint32_t)outs.size();
+  return G16_OK;
+}
+
+// Test-only: the full NZCPPubIdentity(IsLive, MaxToBeSignedBytes, MaxCborArrayLenVC, MaxCborMapLenVC,
+// MaxCborArrayLenCredSubj, MaxCborMapLenCredSubj, CredSubjMaxBufferSpace) constraint system
+// (/root/reference/circuits/nzcptpl.circom:433; nzcp_exampleTest.circom = (0, 314, 0, 4, 2, 4, 5),
+// nzcp_liveTest.circom = (1, 355, 0, 4, 2, 4, 6)) with the CBOR search IN the circuit, its witness for the given
+// ToBeSigned bytes, and a trapdoor proving key.  params = the seven template parameters in that order.
+extern "C" int g16_nzcp_circuit_setup(const uint32_t params[7], const uint8_t* tbs, uint32_t len, uint64_t seed,
+                                      int threads, uint8_t** zkey, size_t* zkey_len, uint8_t** wtns, size_t* wtns_len,
+                                      uint8_t** vkey, size_t* vkey_len, uint8_t** r1cs, size_t* r1cs_len,
+                                      uint32_t* n_constraints) {
+  if (!params || !tbs || params[1] == 0 || params[1] > 503 || params[6] < 2 || params[6] > 6 || len > params[1]) {
+    set_error("nzcp circuit: bad arguments");
+    return G16_E_ARG;
+  }
+  CBuilder cb;
+  cb.nzcp_pub_identity(params[0] != 0, params[1], params[2], params[3], params[4], params[5], params[6], tbs, len);
+  if (n_constraints) *n_constraints = cb.c.m;
+  if (!cb.ok) { set_error("constraint not satisfied: " + cb.fail); return G16_E_STATE; }
+  const int64_t bad = first_unsatisfied_row(cb);
+  if (bad >= 0) { set_error("internal: R1CS row " + std::to_string(bad) + " is not satisfied by the computed witness"); return G16_E_HIP; }
+  if ((uint64_t)cb.c.m + cb.c.p + 1 > ((uint64_t)1 << 27)) { set_error("nzcp circuit too large"); return G16_E_ARG; }
+  if (wtns && wtns_len) {
+    std::vector<FrM> w(cb.w.size());
+    for (size_t i = 0; i < w.size(); i++) w[i] = cb.wire_val((uint32_t)i);
+    Buf b;
+    write_wtns(w, b);
+    *wtns = b.p;
+    *wtns_len = b.len;
+  }
+  if (r1cs && r1cs_len) {
+    Buf b;
+    write_r1cs(cb.c, cb.c.p, 0, b);
+    *r1cs = b.p;
+    *r1cs_len = b.len;
+  }
+  if (zkey && zkey_len) return setup_core(cb.c, seed, threads, zkey, zkey_len, vkey, vkey_len);
+  return G16_OK;
 }
 
 // ------------------------------------------------------------------ .r1cs reader

@@ -167,6 +167,47 @@ def test_config3_batch_nominal(amd):
     prover.close()
 
 
+@pytest.mark.parametrize("which", ["example", "live"])
+def test_real_nzcp_circuit_with_in_circuit_cbor_search(amd, which):
+    """The REAL constraint system of BASELINE configs 1 / 2, built natively (csrc/nzcp_gadgets.h): NZCPPubIdentity
+    with the CBOR search in the circuit -- nzcp_exampleTest.circom on the MoH example pass, nzcp_liveTest.circom on a
+    live-format pass.  GPU proof: public.json equals the reference's golden public signals (example) / the values
+    its test computes from the pass (live: SHA-256 of "given,family,dob", SHA-256 of ToBeSigned, exp:
+    /root/reference/test/nzcp.js:18-49), the proof is accepted by the pairing check against the setup's
+    verification key and equals the CPU oracle's bytes for the same (zkey, wtns, r, s)."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import nzcp_pass
+    from test_cpu_sha256_circuit import example_public_signals, example_to_be_signed
+    if which == "example":
+        tbs, params = example_to_be_signed(), amd.NZCP_EXAMPLE_PARAMS
+        want = [str(x) for x in example_public_signals()]
+    else:
+        tbs, params = nzcp_pass.to_be_signed("Anne-Marie", "Te Whare", "1987-11-30", live=True, exp=1700000000), amd.NZCP_LIVE_PARAMS
+        want = [str(x) for x in _bits_msb_first(hashlib.sha256(b"Anne-Marie,Te Whare,1987-11-30").digest())] + \
+            [str(x) for x in _bits_msb_first(hashlib.sha256(tbs).digest())] + ["1700000000"]
+    out = amd.nzcp_circuit_setup(params, tbs, 77)
+    assert 600_000 < out["n_constraints"] < 1_000_000
+    vk = _vk(out["vkey"])
+    r, s = _rs(77)
+    prover = amd.Prover(out["zkey"])
+    assert prover.info.domain_size == 1 << 20 and prover.info.n_public == P_NZCP
+    proof, pub = prover.prove(out["wtns"], f.le(r), f.le(s))
+    assert pub == want
+    assert _verifies(vk, pub, proof)
+    olib = _oracle_c()
+    obuf = ctypes.create_string_buffer(256)
+    opub = ctypes.create_string_buffer(P_NZCP * 32)
+    assert olib.g16o_prove(out["zkey"], len(out["zkey"]), out["wtns"], len(out["wtns"]), f.le(r), f.le(s), obuf, opub,
+                           os.cpu_count() or 1) == 0
+    pr = amd.Proof()
+    gpub = ctypes.create_string_buffer(P_NZCP * 32)
+    prover.stage(0, out["wtns"])
+    assert prover.prove_staged_raw(0, f.le(r), f.le(s), pr, gpub) == 0
+    assert bytes(pr.a) + bytes(pr.b) + bytes(pr.c) == obuf.raw and gpub.raw == opub.raw
+    prover.close()
+
+
 def _bits_msb_first(data):
     return [str((byte >> (7 - k)) & 1) for byte in data for k in range(8)]
 

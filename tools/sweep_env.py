@@ -13,7 +13,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def main():
     settings = sys.argv[1:] or [""]
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
-    extra = os.environ.get("SWEEP_BENCH_ARGS", "--steps 8 --warmup 3 --no-cpu --batch-proofs 24").split()
+    extra = os.environ.get("SWEEP_BENCH_ARGS", "--steps 40 --warmup 5 --no-cpu --batch-streams 0").split()
     with open(os.path.join(ROOT, "gpurun_out", "sweep.txt"), "a") as log:
         for st in settings:
             env = dict(os.environ)
@@ -27,7 +27,8 @@ def main():
                 d = json.loads(line)
                 bt = d.get("batch_throughput") or {}
                 ph = d["phases_ms"]
-                msg = (f"{st or 'default':50s} single {d['ms_per_step']:7.3f} ms  batch {bt.get('ms_per_proof', 0):7.3f} ms  "
+                p50, mn = d.get("ms_per_step_p50_min", [0, 0])
+                msg = (f"{st or 'default':50s} single {d['ms_per_step']:7.3f} (p50 {p50:6.3f} min {mn:6.3f}) ms  batch {bt.get('ms_per_proof', 0):7.3f} ms  "
                        f"qap {ph['qap']:.2f} ntt {ph['ntt_x6_join']:.2f} msmW/G2/H {ph['msm_A_B1_B2_C_H'][0]:.2f}/"
                        f"{ph['msm_A_B1_B2_C_H'][2]:.2f}/{ph['msm_A_B1_B2_C_H'][4]:.2f}")
             except Exception as e:  # noqa: BLE001
