@@ -393,15 +393,17 @@ template <class C = Fq29C> G16_HD bool f29_is_zero(const F29& a) {
   for (int i = 0; i < 9; i++) { z |= y.l[i]; e |= y.l[i] ^ C::P[i]; }
   return z == 0 || e == 0;
 }
-// cheap necessary condition for x == 0 (mod p) when x < (KMAX+1)*p: the low limb is exact after
-// the carry ripple, and x = k*p forces it to k*p mod 2^29.
+// cheap necessary condition for x == 0 (mod p) when x < (KMAX+1)*p: the two low limbs are exact after the carry
+// ripple, and x = k*p forces them to the low 58 bits of k*p.  (One limb alone fires on 2^-26 of ordinary values:
+// with ~3 x 10^7 bucket additions per MSM launch that is a spurious redo task in every third launch, each
+// costing a wavefront of complete additions on the critical chain; two limbs: 2^-55.)
 template <int KMAX, class C = Fq29C> G16_HD bool f29_maybe_zero(const F29& a) {
   bool hit = false;
-  uint32_t kp = 0;
+  const uint64_t p01 = (uint64_t)C::P[0] | ((uint64_t)C::P[1] << 29);   // p mod 2^58
 #pragma unroll
   for (int k = 0; k <= KMAX; k++) {
-    hit |= (a.l[0] == (kp & kM29));
-    kp += C::P[0];
+    const uint64_t kp = (uint64_t)k * p01;
+    hit |= (a.l[0] == (uint32_t)(kp & kM29)) & (a.l[1] == (uint32_t)((kp >> 29) & kM29));
   }
   return hit;
 }

@@ -115,6 +115,11 @@ struct MsmGroup {
   uint32_t B = 0;               // buckets per row 2^(c-1)
   uint32_t low_bits = 0, bins = 1;   // bucket = bin << low_bits | low: the two levels of the sort
   bool ones = false;            // extra unweighted row per section for the scalars equal to 1 (witness groups)
+  // The TOP scalar window holds only 254 - c (Ws - 1) bits (7 of 12 at c = 13, and r >> 247 = 48: 49 buckets would
+  // take every full-width scalar's top digit -- thousands of entries, ~150 task partials each, a latency-bound
+  // wavefront-per-bucket combine: r02, 1.1 ms on the G2 lane of the real NZCP witness).  Its digits are spread
+  // instead: bucket = (digit - 1) << salt_bits | (point index & mask), every bucket of a digit weighted alike.
+  uint32_t salt_bits = 0;
   uint32_t rps = 0, rows = 0;   // rows per section (W + ones), rows in total
   uint32_t task_len = 0;        // of the G1 lane
   bool task_len_forced = false; // MsmConfig::task_len given: every lane uses it

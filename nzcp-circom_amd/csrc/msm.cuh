@@ -52,6 +52,7 @@ struct MsmPlan {
   uint32_t sec_begin[kMsmMaxSections];
   int c, Ws;
   uint32_t W, pf, B, low_bits, bins, rps, rows, ones;
+  uint32_t salt_bits;   // see MsmGroup::salt_bits
 };
 
 // Everything downstream of the sort exists once per curve ("lane"): lane 0 = G1 over every key of the group,
@@ -78,7 +79,8 @@ struct MsmLaneWs {
   uint32_t* d_redo = nullptr;        // tasks whose fast-path sum met an exceptional case
   void* d_partial = nullptr;         // one XYZZ per task
   void* d_bsum = nullptr;            // one XYZZ per bucket cut into several tasks
-  uint32_t* d_heavy = nullptr;       // [0] = count, [1..] = buckets with more than light_max partials
+  uint32_t* d_heavy = nullptr;       // [0] = count, [1..] = buckets with more than kMediumTasks partials
+  uint32_t* d_medium = nullptr;      // the same for light_max < partials <= kMediumTasks
   uint32_t max_heavy = 0;
   void* d_seg = nullptr;
   void* d_red = nullptr;
@@ -132,9 +134,15 @@ inline uint32_t msm_seg_len_cfg(int which) {
   return cfg.v[which];
 }
 
+// The latency-bound tail kernels (combine, reduce, tree) run 256-thread workgroups: the four wavefronts of a
+// workgroup sit on one CU and walk the same ~100 KB of unrolled point-addition code together, sharing its
+// instruction-cache lines (64-thread workgroups scattered one lonely wavefront per CU: r01 measured 71 cycles per
+// instruction on the G2 reduce).
+static constexpr uint32_t kTailThreads = 256;
 static constexpr uint32_t kRemClasses = 32;   // remainder tasks are queued by relative length, longest class first
 static constexpr uint32_t kTaskChunk = 64;
-static constexpr uint32_t kLightTasks = 6;    // buckets with more partials take the wavefront path (floor)
+static constexpr uint32_t kLightTasks = 3;    // lower bound of the light/other split (sizes the bucket lists)
+static constexpr uint32_t kMediumTasks = 64;  // up to this many partials: a 16-lane group per bucket
 
 // front end + queue construction (msm_g1.hip)
 int msm_front_end(const MsmGroup& g, MsmWorkspace* ws, const Fr* d_scalars, hipStream_t st);
@@ -237,8 +245,9 @@ __global__ __launch_bounds__(64, F::kAccumWavesPerSimd) void msm_accumulate_kern
   }
 }
 
-// The flagged tasks again, with the complete addition (doubling, cancellation, infinity): a handful per
-// proof at most, one lane each.
+// The flagged tasks again, with the complete addition (doubling, cancellation, infinity): a handful per proof at
+// most.  One wavefront per task: the lanes take its entries (the first addition into an empty accumulator is a
+// copy), then a shuffle tree of complete additions -- ~6 sequential additions instead of task_len.
 template <class F>
 __global__ __launch_bounds__(64) void msm_redo_kernel(const PackedAffine<F>* __restrict__ bases,
                                                       const uint32_t* __restrict__ sorted, uint32_t point_base,
@@ -247,19 +256,24 @@ __global__ __launch_bounds__(64) void msm_redo_kernel(const PackedAffine<F>* __r
                                                       const uint32_t* __restrict__ redo,
                                                       XYZZ<F>* __restrict__ partial) {
   const uint32_t count = queue[1];
-  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < count; i += gridDim.x * blockDim.x) {
+  const uint32_t lane = threadIdx.x;
+  for (uint32_t i = blockIdx.x; i < count; i += gridDim.x) {
     const uint32_t t = redo[i];
     const uint2 d = task_desc[t];
     XYZZ<F> acc;
     x29_set_inf(acc);
-    for (uint32_t e = d.x; e < d.x + d.y; e++) {
+    for (uint32_t e = d.x + lane; e < d.x + d.y; e += 64) {
       const uint32_t idx = sorted[e];
       Affine<F> p;
       a29_unpack(p, bases[(idx & 0x7fffffffu) - point_base]);
       if (idx >> 31) a29_neg(p);
       x29_madd(acc, p);
     }
-    partial[t] = acc;
+    for (int s = 32; s >= 1; s >>= 1) {
+      const XYZZ<F> q = xyzz_shfl_down(acc, s);
+      x29_add(acc, q);
+    }
+    if (lane == 0) partial[t] = acc;
   }
 }
 
@@ -273,13 +287,13 @@ __device__ __forceinline__ void msm_mul_small(XYZZ<F>& r, const XYZZ<F>& p, uint
   }
 }
 
-template <class F> __device__ __forceinline__ XYZZ<F> xyzz_shfl_down(const XYZZ<F>& p, int delta) {
+template <class F, int WIDTH = 64> __device__ __forceinline__ XYZZ<F> xyzz_shfl_down(const XYZZ<F>& p, int delta) {
   XYZZ<F> r;
   constexpr int NW = sizeof(XYZZ<F>) / 4;
   const uint32_t* s = reinterpret_cast<const uint32_t*>(&p);
   uint32_t* d = reinterpret_cast<uint32_t*>(&r);
 #pragma unroll
-  for (int i = 0; i < NW; i++) d[i] = __shfl_down(s[i], delta, 64);
+  for (int i = 0; i < NW; i++) d[i] = __shfl_down(s[i], delta, WIDTH);
   return r;
 }
 
@@ -287,19 +301,21 @@ template <class F> __device__ __forceinline__ XYZZ<F> xyzz_shfl_down(const XYZZ<
 // partials: a lane per bucket; more: queued for the wavefront kernel).  A bucket with one task needs no pass at
 // all -- the reduce kernel reads its partial sum directly (msm_bucket_value).
 template <class F>
-__global__ __launch_bounds__(64) void msm_combine_light_kernel(const XYZZ<F>* __restrict__ partial,
+__global__ __launch_bounds__(kTailThreads) void msm_combine_light_kernel(const XYZZ<F>* __restrict__ partial,
                                                                const uint32_t* __restrict__ toff, uint32_t nbk,
                                                                XYZZ<F>* __restrict__ bsum,
                                                                uint32_t* __restrict__ heavy, uint32_t max_heavy,
+                                                               uint32_t* __restrict__ medium,
                                                                uint32_t light_max) {
   const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= nbk) return;
   const uint32_t t0 = toff[b], t1 = toff[b + 1];
   if (t1 - t0 < 2) return;
-  if (t1 - t0 > light_max) {
-    const uint32_t k = atomicAdd(&heavy[0], 1u);
-    if (k < max_heavy) heavy[1 + k] = b;   // cannot overflow: max_heavy >= max_tasks / kLightTasks
-    return;                                // bsum written by the heavy kernel
+  if (t1 - t0 > light_max) {               // bsum written by the medium / heavy kernel
+    uint32_t* list = (t1 - t0 <= kMediumTasks) ? medium : heavy;
+    const uint32_t k = atomicAdd(&list[0], 1u);
+    if (k < max_heavy) list[1 + k] = b;    // cannot overflow: max_heavy >= max_tasks / light_max
+    return;
   }
   XYZZ<F> acc = partial[t0];
   for (uint32_t t = t0 + 1; t < t1; t++) {
@@ -309,16 +325,51 @@ __global__ __launch_bounds__(64) void msm_combine_light_kernel(const XYZZ<F>* __
   bsum[b] = acc;
 }
 
+// Buckets with light_max < partials <= 64: FOUR buckets per wavefront, 16 lanes each -- up to four partials per
+// lane, then a 4-step tree inside the 16-lane group.  (The real NZCP witness is made of few distinct values repeated hundreds of
+// times -- the inverses 1/(i - index) of its QuinSelector comparisons -- so its buckets are few and hold ~10 task
+// partials each: a whole wavefront per bucket spent 4 additions on 11 useful lanes, r02: 1.1 ms on the G2 lane.)
+template <class F>
+__global__ __launch_bounds__(kTailThreads) void msm_combine_medium_kernel(const XYZZ<F>* __restrict__ partial,
+                                                                const uint32_t* __restrict__ toff,
+                                                                XYZZ<F>* __restrict__ bsum,
+                                                                const uint32_t* __restrict__ medium, uint32_t max_heavy) {
+  uint32_t count = medium[0];
+  if (count > max_heavy) count = max_heavy;
+  const uint32_t lane = threadIdx.x & 63u, sub = lane >> 4, l = lane & 15u;
+  const uint32_t wpb = blockDim.x >> 6;
+  for (uint32_t h0 = (blockIdx.x * wpb + (threadIdx.x >> 6)) * 4; h0 < count; h0 += gridDim.x * wpb * 4) {
+    const uint32_t h = h0 + sub;
+    XYZZ<F> acc;
+    x29_set_inf(acc);
+    uint32_t b = 0;
+    if (h < count) {
+      b = medium[1 + h];
+      const uint32_t t0 = toff[b], t1 = toff[b + 1];
+      for (uint32_t t = t0 + l; t < t1; t += 16) {   // <= 4 per lane; the first lands in an empty accumulator: a copy
+        const XYZZ<F> sp = partial[t];
+        x29_add(acc, sp);
+      }
+    }
+    for (int d = 8; d >= 1; d >>= 1) {
+      const XYZZ<F> q = xyzz_shfl_down<F, 16>(acc, d);
+      x29_add(acc, q);
+    }
+    if (h < count && l == 0) bsum[b] = acc;
+  }
+}
+
 // One wavefront per heavy bucket: lanes stride over the partials, then a 6-step shuffle tree.
 template <class F>
-__global__ __launch_bounds__(64) void msm_combine_heavy_kernel(const XYZZ<F>* __restrict__ partial,
+__global__ __launch_bounds__(kTailThreads) void msm_combine_heavy_kernel(const XYZZ<F>* __restrict__ partial,
                                                                const uint32_t* __restrict__ toff,
                                                                XYZZ<F>* __restrict__ bsum,
                                                                const uint32_t* __restrict__ heavy, uint32_t max_heavy) {
   uint32_t count = heavy[0];
   if (count > max_heavy) count = max_heavy;
-  const uint32_t lane = threadIdx.x;
-  for (uint32_t h = blockIdx.x; h < count; h += gridDim.x) {
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint32_t wpb = blockDim.x >> 6;
+  for (uint32_t h = blockIdx.x * wpb + (threadIdx.x >> 6); h < count; h += gridDim.x * wpb) {
     const uint32_t b = heavy[1 + h];
     const uint32_t t0 = toff[b], t1 = toff[b + 1];
     XYZZ<F> acc;
@@ -351,16 +402,19 @@ __device__ __forceinline__ XYZZ<F> msm_bucket_value(const XYZZ<F>* __restrict__ 
 
 // seg[j*nseg + g] = sum_{bi in segment g of row j} (bi+1) * S_bi;  ones rows (j % rps == W): plain sum S_bi
 template <class F>
-__global__ __launch_bounds__(64) void msm_bucket_reduce_kernel(const XYZZ<F>* __restrict__ partial,
+__global__ __launch_bounds__(kTailThreads) void msm_bucket_reduce_kernel(const XYZZ<F>* __restrict__ partial,
                                                                const XYZZ<F>* __restrict__ bsum,
                                                                const uint32_t* __restrict__ toff,
                                                                uint32_t B, uint32_t nseg, uint32_t rows, uint32_t rps,
-                                                               uint32_t W, uint32_t ones, uint32_t seg_len,
-                                                               XYZZ<F>* __restrict__ seg) {
+                                                               uint32_t W, uint32_t ones, uint32_t salt_bits,
+                                                               uint32_t seg_len, XYZZ<F>* __restrict__ seg) {
   const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
   if (tid >= rows * nseg) return;
   const uint32_t j = tid / nseg, g = tid % nseg;
   const bool plain = ones && (j % rps == W);   // the "ones" pseudo-window: plain sum of its buckets
+  // the salted top window: 2^salt_bits consecutive buckets share the weight (index >> salt_bits) + 1, and a
+  // segment never straddles two weights (seg_len divides 2^salt_bits)
+  const bool salted = salt_bits && (j % rps == W - 1);
   const uint32_t lo = g * seg_len;
   const uint32_t hi = (lo + seg_len < B) ? lo + seg_len : B;
   XYZZ<F> run, acc;
@@ -369,10 +423,12 @@ __global__ __launch_bounds__(64) void msm_bucket_reduce_kernel(const XYZZ<F>* __
   for (uint32_t bi = hi; bi-- > lo;) {
     const XYZZ<F> s = msm_bucket_value<F>(partial, bsum, toff, j * B + bi);
     x29_add(run, s);
-    if (!plain) x29_add(acc, run);
+    if (!plain && !salted) x29_add(acc, run);
   }
   if (plain) {
     acc = run;
+  } else if (salted) {
+    msm_mul_small(acc, run, (lo >> salt_bits) + 1);
   } else if (lo != 0) {
     XYZZ<F> m;
     msm_mul_small(m, run, lo);
@@ -383,9 +439,10 @@ __global__ __launch_bounds__(64) void msm_bucket_reduce_kernel(const XYZZ<F>* __
 
 // out[j*nout + blk] = sum of in[j*nin + blk*64 .. +64)
 template <class F>
-__global__ __launch_bounds__(64) void msm_wave_reduce_kernel(const XYZZ<F>* __restrict__ in, uint32_t nin,
+__global__ __launch_bounds__(kTailThreads) void msm_wave_reduce_kernel(const XYZZ<F>* __restrict__ in, uint32_t nin,
                                                              XYZZ<F>* __restrict__ out, uint32_t nout) {
-  const uint32_t j = blockIdx.y, blk = blockIdx.x, lane = threadIdx.x;
+  const uint32_t j = blockIdx.y, blk = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), lane = threadIdx.x & 63u;
+  if (blk >= nout) return;   // whole wavefronts leave together
   const uint32_t i = blk * 64 + lane;
   XYZZ<F> p;
   if (i < nin) p = in[(size_t)j * nin + i];
@@ -434,16 +491,12 @@ __global__ __launch_bounds__(64) void msm_to_canon_kernel(const XYZZ<F>* __restr
   out[i] = r;
 }
 
-// light/heavy split of the combine pass: the lane-per-bucket path takes up to ~2x the average number of task
-// partials per bucket (a few sequential adds), the wavefront path only the outliers
-inline uint32_t msm_light_max(const MsmLaneWs& ln) {
-  const uint64_t nbk = (uint64_t)ln.key_hi - ln.key_lo;
-  const uint64_t avg = ln.max_tasks / (nbk ? nbk : 1) + 1;
-  uint64_t v = 2 * avg + 4;
-  if (v < kLightTasks) v = kLightTasks;
-  if (v > 48) v = 48;
-  return (uint32_t)v;
-}
+// light/heavy split of the combine pass.  A lane sums the partials of a "light" bucket one after the other, so ONE
+// bucket with many partials holds its whole wavefront (and, these kernels being latency-bound, the kernel) for
+// that many sequential additions: r02, real NZCP witness, light_max = 18 -> 17 G2 additions = 1.15 ms for a
+// kernel whose typical bucket has 2 partials.  Everything beyond a few partials takes the wavefront-per-bucket
+// tree instead (its steps above the partial count cost nothing: an addition of infinity returns at once).
+inline uint32_t msm_light_max(const MsmLaneWs& ln) { return ln.curve == 2 ? 3u : 4u; }
 
 // ------------------------------------------------------------------ one lane, after the sort (per curve)
 // Enqueues queue construction, accumulate, combine, reduce and the copy of the row sums on `st`.
@@ -480,14 +533,20 @@ int msm_launch_lane_t(const MsmGroup& g, MsmWorkspace* ws, MsmLaneWs& ln, const 
   msm_redo_kernel<F><<<64, 64, 0, st>>>((const PackedAffine<F>*)d_bases, ws->d_sorted, ln.point_base, ln.d_task_desc,
                                         ln.d_queue, ln.d_redo, (PT*)ln.d_partial);
   G16_HIP(hipMemsetAsync(ln.d_heavy, 0, 4, st));
-  msm_combine_light_kernel<F><<<(nbk + 63) / 64, 64, 0, st>>>((const PT*)ln.d_partial, ln.d_toff, nbk,
-                                                              (PT*)ln.d_bsum, ln.d_heavy, ln.max_heavy, msm_light_max(ln));
-  msm_combine_heavy_kernel<F><<<1024, 64, 0, st>>>((const PT*)ln.d_partial, ln.d_toff, (PT*)ln.d_bsum,
+  G16_HIP(hipMemsetAsync(ln.d_medium, 0, 4, st));
+  msm_combine_light_kernel<F><<<(nbk + kTailThreads - 1) / kTailThreads, kTailThreads, 0, st>>>((const PT*)ln.d_partial, ln.d_toff, nbk,
+                                                              (PT*)ln.d_bsum, ln.d_heavy, ln.max_heavy, ln.d_medium,
+                                                              msm_light_max(ln));
+  msm_combine_medium_kernel<F><<<1024, kTailThreads, 0, st>>>((const PT*)ln.d_partial, ln.d_toff, (PT*)ln.d_bsum, ln.d_medium,
+                                                              ln.max_heavy);
+  // one wavefront per heavy bucket, all at once (a real NZCP witness puts thousands of entries into the buckets of
+  // its byte-valued scalars and of the narrow top window: r02, 1 024 looping wavefronts took 3 rounds)
+  msm_combine_heavy_kernel<F><<<2048, kTailThreads, 0, st>>>((const PT*)ln.d_partial, ln.d_toff, (PT*)ln.d_bsum,
                                                    ln.d_heavy, ln.max_heavy);
   mark(1);
-  msm_bucket_reduce_kernel<F><<<(ln.rows * nseg + 63) / 64, 64, 0, st>>>((const PT*)ln.d_partial, (const PT*)ln.d_bsum,
+  msm_bucket_reduce_kernel<F><<<(ln.rows * nseg + kTailThreads - 1) / kTailThreads, kTailThreads, 0, st>>>((const PT*)ln.d_partial, (const PT*)ln.d_bsum,
                                                                         ln.d_toff, g.B, nseg, ln.rows, g.rps,
-                                                                        (uint32_t)g.W, g.ones ? 1u : 0u, seg_len,
+                                                                        (uint32_t)g.W, g.ones ? 1u : 0u, g.salt_bits, seg_len,
                                                                         (PT*)ln.d_seg);
   mark(2);
   // tree: d_seg (nseg per row) -> ... -> 1 per row, ping-pong between d_red halves
@@ -497,7 +556,7 @@ int msm_launch_lane_t(const MsmGroup& g, MsmWorkspace* ws, MsmLaneWs& ln, const 
   int flip = 0;
   while (cnt > 1) {
     const uint32_t nout = (cnt + 63) / 64;
-    msm_wave_reduce_kernel<F><<<dim3(nout, ln.rows), 64, 0, st>>>(cur, cnt, bufs[flip], nout);
+    msm_wave_reduce_kernel<F><<<dim3((nout + 3) / 4, ln.rows), kTailThreads, 0, st>>>(cur, cnt, bufs[flip], nout);
     cur = bufs[flip];
     flip ^= 1;
     cnt = nout;

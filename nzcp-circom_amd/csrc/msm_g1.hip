@@ -100,7 +100,8 @@ static __global__ __launch_bounds__(kBinThreads) void msm_bin_pass_kernel(const 
       const int32_t d = (j == Ws - 1) ? (int32_t)e : (int32_t)e - (int32_t)pl.B;   // the top window stays unsigned
       if (d != 0) {
         const uint32_t neg = d < 0 ? 1u : 0u;
-        const uint32_t bucket = (d < 0 ? (uint32_t)(-d) : (uint32_t)d) - 1u;
+        uint32_t bucket = (d < 0 ? (uint32_t)(-d) : (uint32_t)d) - 1u;
+        if (pl.salt_bits && j == Ws - 1) bucket = (bucket << pl.salt_bits) | (i & ((1u << pl.salt_bits) - 1));
         const uint32_t r = pl.pf > 1 ? j % pl.W : j;
         const uint32_t eidx = pl.pf > 1 ? (j / pl.W) * pl.n + i : g;
         const uint32_t rb = (row0 + r) * pl.bins + (bucket >> pl.low_bits);
@@ -428,6 +429,7 @@ static MsmPlan msm_plan_of(const MsmGroup& g) {
   pl.rps = g.rps;
   pl.rows = g.rows;
   pl.ones = g.ones ? 1u : 0u;
+  pl.salt_bits = g.salt_bits;
   return pl;
 }
 
@@ -578,6 +580,14 @@ int msm_group_create(MsmGroup& g, const MsmSectionIn* secs, int nsec, const MsmC
   if ((uint64_t)g.pf * g.n >= 0x7fffffffull) { set_error("msm: too many precomputed bases"); return G16_E_ARG; }
   g.B = 1u << (g.c - 1);
   g.ones = !cfg.dense;
+  {
+    // salted top window (see MsmGroup::salt_bits): only without window precomputation (a row = one window), when
+    // the top window is narrow enough to leave >= 4 salt bits (reduce segments of up to 16 buckets stay inside one
+    // weight)
+    const int top_bits = 254 - g.c * (g.Ws - 1);
+    const bool salt_off = getenv("G16_NO_SALT") && atoi(getenv("G16_NO_SALT"));
+    if (g.pf == 1 && top_bits >= 1 && (g.c - 1) - top_bits >= 4 && !salt_off) g.salt_bits = (uint32_t)((g.c - 1) - top_bits);
+  }
   g.rps = (uint32_t)g.W + (g.ones ? 1u : 0u);
   g.rows = (uint32_t)nsec * g.rps;
   // two-level sort: bucket = bin << low_bits | low; 8 low bits unless that leaves too many (row, bin) counters
@@ -655,6 +665,10 @@ static int lane_create(MsmLaneWs& ln, const MsmGroup& g, int curve, uint32_t key
     ln.task_len = (uint32_t)(t < 8 ? 8 : (t > 32 ? 32 : t));
   }
   ln.seg_len = msm_seg_len_cfg(curve == 2 ? 1 : (g.dense ? 2 : 0));
+  if (g.salt_bits) {   // a segment must not straddle two weights of the salted top window
+    while (ln.seg_len > (1u << g.salt_bits) || ((1u << g.salt_bits) % ln.seg_len) != 0) ln.seg_len >>= 1;
+    if (ln.seg_len == 0) ln.seg_len = 1;
+  }
   // every non-empty bucket has <= 1 short task + entries / task_len full ones
   ln.max_tasks = nbk + entries / ln.task_len + 64;
   const size_t pb = curve == 2 ? sizeof(G2XYZZ29) : sizeof(G1XYZZ29);   // device-side (lazy) points
@@ -676,6 +690,7 @@ static int lane_create(MsmLaneWs& ln, const MsmGroup& g, int curve, uint32_t key
   G16_HIP(hipMalloc(&ln.d_bsum, nbk * pb + 256));
   ln.max_heavy = (uint32_t)(ln.max_tasks / kLightTasks + 16);
   G16_HIP(hipMalloc(&ln.d_heavy, ((size_t)ln.max_heavy + 2) * 4));
+  G16_HIP(hipMalloc(&ln.d_medium, ((size_t)ln.max_heavy + 2) * 4));
   G16_HIP(hipMalloc(&ln.d_seg, (size_t)ln.rows * nseg * pb + 256));
   G16_HIP(hipMalloc(&ln.d_red, 2 * (size_t)ln.rows * ((nseg + 63) / 64) * pb + 256));
   ln.out_bytes = (size_t)ln.rows * cpb;
@@ -688,7 +703,7 @@ static int lane_create(MsmLaneWs& ln, const MsmGroup& g, int curve, uint32_t key
 }
 
 static void lane_destroy(MsmLaneWs& ln) {
-  void* ptrs[] = {ln.d_task_desc, ln.d_qdesc, ln.d_class, ln.d_queue, ln.d_redo, ln.d_partial, ln.d_bsum, ln.d_heavy,
+  void* ptrs[] = {ln.d_task_desc, ln.d_qdesc, ln.d_class, ln.d_queue, ln.d_redo, ln.d_partial, ln.d_bsum, ln.d_heavy, ln.d_medium,
                   ln.d_seg, ln.d_red, ln.d_canon, ln.d_off, ln.d_toff, ln.d_foff, ln.d_tile_a, ln.d_tile_b, ln.d_tile_c};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
