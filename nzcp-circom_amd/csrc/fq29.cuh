@@ -505,7 +505,10 @@ struct alignas(8) F29x2 {
 };
 
 // Field-ops bundles for ec29.cuh.  sub/neg carry the multiple of p that covers the subtrahend.
+struct Fq29TailOps;
+struct Fq2x29TailOps;
 struct Fq29Ops {
+  using Tail = Fq29TailOps;   // field ops of the latency-bound tail kernels (see the end of this file)
   using T = F29;
   using Canon = Fq;   // canonical twin (fp.cuh)
   using CanonOps = FqOps;
@@ -528,6 +531,7 @@ struct Fq29Ops {
 };
 
 struct Fq2x29Ops {
+  using Tail = Fq2x29TailOps;
   using T = F29x2;
   using Canon = Fq2;
   using CanonOps = Fq2Ops;
@@ -560,5 +564,13 @@ struct Fq2x29Ops {
   static G16_HD T from_canon(const Fq2& x) { return T{f29_from_fq(x.a), f29_from_fq(x.b)}; }
   static G16_HD Fq2 to_canon(const T& x) { return Fq2{f29_to_fq(x.a), f29_to_fq(x.b)}; }
 };
+
+
+// Field ops of the latency-bound MSM tail kernels (combine, bucket reduce, trees).  They are the inlined ops: calling
+// ONE out-of-line copy of the products instead (the hypothesis being instruction-cache misses of lone wavefronts on
+// ~80 KB of unrolled G2 code) was measured in r02 and made the G2 tails 10-25 % SLOWER -- a G2 addition simply is
+// ~10 k instructions at the ~11 cycles per instruction a lone wavefront issues at (~46 us).
+struct Fq29TailOps : Fq29Ops {};
+struct Fq2x29TailOps : Fq2x29Ops {};
 
 }  // namespace g16

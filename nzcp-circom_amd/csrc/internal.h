@@ -120,7 +120,16 @@ struct MsmGroup {
   // wavefront-per-bucket combine: r02, 1.1 ms on the G2 lane of the real NZCP witness).  Its digits are spread
   // instead: bucket = (digit - 1) << salt_bits | (point index & mask), every bucket of a digit weighted alike.
   uint32_t salt_bits = 0;
-  uint32_t rps = 0, rows = 0;   // rows per section (W + ones), rows in total
+  // REPEATED scalar values (witness groups).  A circom witness is made of few distinct values: 63 % zeros, 16 % ones
+  // and -- the real NZCP witness, r02 -- 174 k full-width words that are only 663 distinct inverses 1/(i - index) of
+  // its QuinSelector comparisons.  Points whose scalar value is shared by >= kDupMin points of the section take one
+  // entry in a "dup" row (bucket = a hash of the value; a bucket qualifies when every scalar in it is equal, checked
+  // exactly) instead of one entry per window: sum_i s P_i = s (sum_i P_i).  The bucket sums T are then combined by
+  // bit position (U_b = sum of the T whose value has bit b, one shuffle tree per bit) and the host runs Horner over
+  // the 254 bit sums.  dup_rows rows of B hash buckets follow the digit (+ ones) rows of every section.
+  uint32_t dup_rows = 0;        // 0 = off
+  uint32_t dup_bits = 0;        // log2(dup_rows * B) hash buckets per section
+  uint32_t rps = 0, rows = 0;   // rows per section (W + ones + dup_rows), rows in total
   uint32_t task_len = 0;        // of the G1 lane
   bool task_len_forced = false; // MsmConfig::task_len given: every lane uses it
   bool dense = true;
@@ -137,6 +146,9 @@ struct MsmResult {
   G1XYZZ g1[kMsmMaxSections];
   G2XYZZ g2;
 };
+static constexpr uint32_t kDupMin = 8;       // points sharing a value before the dup row pays (1 entry + ~127 tree
+                                             // additions per value against one entry per window)
+static constexpr uint32_t kDupBitRows = 254; // bit positions of a scalar
 // msm_launch only enqueues: front end + G1 lane on `st`, the G2 lane (if any) forks onto `st2` after the sort
 // (st2 == nullptr or == st: same stream).  msm_collect waits for both, folds the window sums on the host
 // (Horner, c doublings per row) and fills `out`.  One launch in flight per workspace.
@@ -146,7 +158,8 @@ int msm_launch(const MsmGroup& g, MsmWorkspace* ws, const Fr* d_scalars, hipStre
 int msm_launch_front(const MsmGroup& g, MsmWorkspace* ws, const Fr* d_scalars, hipStream_t st);
 int msm_launch_lanes(const MsmGroup& g, MsmWorkspace* ws, hipStream_t st, hipStream_t st2, hipEvent_t gate1,
                      hipEvent_t gate2);
-hipEvent_t msm_event(MsmWorkspace* ws, int which);   // 0 = sort done, 1 / 2 = G1 accumulate kernel started / done
+void msm_set_quota(MsmWorkspace* ws, uint32_t quota_g1, uint32_t quota_g2);   // accumulate wavefronts retire after this many chunks of 64 tasks (0 = persistent)
+hipEvent_t msm_event(MsmWorkspace* ws, int which);   // 0 = sort done, 1 / 2 = G1 accumulate kernel started / done, 3 / 4 = G1 / G2 lane done (nullptr: no such lane)
 int msm_collect(const MsmGroup& g, MsmWorkspace* ws, MsmResult* out);
 float msm_last_accum_ms(const MsmWorkspace* ws, int lane);        // lane 0 = G1, 1 = G2: the accumulate kernel alone
 void msm_set_waves(MsmWorkspace* ws, uint32_t waves_g1, uint32_t waves_g2);   // persistent accumulate grids, wavefronts per SIMD (0 = full occupancy)
@@ -161,6 +174,16 @@ template <class F> inline void msm_combine_windows(XYZZ<F>& total, const XYZZ<F>
     xyzz_add(total, windows[j]);
   }
   if (ones) xyzz_add(total, windows[W]);
+}
+// total += sum_b 2^b * bits[b]  (the dup rows' bit-position sums: Horner, one doubling per bit)
+template <class F> inline void msm_add_bit_sums(XYZZ<F>& total, const XYZZ<F>* bits) {
+  XYZZ<F> acc;
+  xyzz_set_inf(acc);
+  for (int b = (int)kDupBitRows - 1; b >= 0; b--) {
+    if (!xyzz_is_inf(acc)) xyzz_dbl(acc);
+    xyzz_add(acc, bits[b]);
+  }
+  xyzz_add(total, acc);
 }
 
 }  // namespace g16

@@ -53,7 +53,20 @@ struct MsmPlan {
   int c, Ws;
   uint32_t W, pf, B, low_bits, bins, rps, rows, ones;
   uint32_t salt_bits;   // see MsmGroup::salt_bits
+  uint32_t dup_rows, dup_bits;   // see MsmGroup::dup_rows
 };
+
+// the hash bucket of a scalar value in its section's dup rows
+__host__ __device__ __forceinline__ uint32_t msm_dup_hash(const uint32_t x[8], uint32_t bits) {
+  uint64_t h = 0x9E3779B97F4A7C15ull;
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    h ^= (uint64_t)x[2 * k] | ((uint64_t)x[2 * k + 1] << 32);
+    h *= 0xBF58476D1CE4E5B9ull;
+    h ^= h >> 29;
+  }
+  return (uint32_t)(h >> 24) & ((1u << bits) - 1);
+}
 
 // Everything downstream of the sort exists once per curve ("lane"): lane 0 = G1 over every key of the group,
 // lane 1 = G2 over the keys of the section it rides on.
@@ -84,7 +97,14 @@ struct MsmLaneWs {
   uint32_t max_heavy = 0;
   void* d_seg = nullptr;
   void* d_red = nullptr;
-  void* d_canon = nullptr;           // `rows` canonical XYZZ row sums
+  void* d_canon = nullptr;           // `rows` canonical XYZZ row sums, then nsec_lane * 254 bit sums of the dup rows
+  void* d_dseg = nullptr;            // dup rows: per (section, bit, chunk of 64 hash buckets) sums
+  void* d_dred = nullptr;            // ... and their tree
+  hipStream_t st_dup = nullptr;      // the dup-row stage runs beside the bucket reduce of the digit rows
+  hipEvent_t ev_dup_fork = nullptr, ev_dup_join = nullptr;
+  uint32_t* d_dcount = nullptr;      // [nsec_lane] qualifying non-empty dup buckets
+  uint32_t* d_dlist = nullptr;       // [nsec_lane][2^dup_bits] their hash-bucket ids, compacted
+  uint32_t nsec_lane = 0;            // sections this lane covers (G1: all, G2: one)
   uint8_t* h_pinned = nullptr;
   size_t out_bytes = 0;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;   // around the bucket-accumulate kernel
@@ -94,6 +114,7 @@ struct MsmLaneWs {
   // scheduling of the next launch (msm_launch_lanes / msm_set_waves)
   hipEvent_t gate = nullptr;         // the accumulate kernel waits for this event (nullptr: none)
   uint32_t waves_per_simd = 0;       // persistent accumulate grid, 0 = the kernel's full occupancy
+  uint32_t chunk_quota = 0;          // 0 = persistent wavefronts; k = wavefronts retire after k chunks of 64 tasks
 };
 
 struct MsmWorkspace {
@@ -105,6 +126,11 @@ struct MsmWorkspace {
   uint32_t* d_sorted = nullptr;      // final list: table index | sign << 31, grouped by bucket key
   uint32_t* d_cnt = nullptr;         // [nb] bucket populations
   uint32_t nb = 0;
+  // repeated-value detection (MsmGroup::dup_rows): per section and hash bucket
+  uint32_t* d_dup_cnt = nullptr;     // points hashed there (scalars other than 0 and 1)
+  uint32_t* d_dup_rep = nullptr;     // one of them (global point index), 0xffffffff = none
+  uint32_t* d_dup_mixed = nullptr;   // != 0: the bucket holds different values -> not used
+  const Fr* d_scalars = nullptr;     // of the running launch
   MsmLaneWs lane[2];
   hipEvent_t ev_sorted = nullptr;    // sort + scans done: the lanes may start
   hipEvent_t trace_ev[4] = {};       // G16_TRACE_HOST: pass 0, bin scans, pass 1, bin sort
@@ -139,6 +165,11 @@ inline uint32_t msm_seg_len_cfg(int which) {
 // instruction-cache lines (64-thread workgroups scattered one lonely wavefront per CU: r01 measured 71 cycles per
 // instruction on the G2 reduce).
 static constexpr uint32_t kTailThreads = 256;
+// kLatencyPrio: every kernel of the MSM except the bucket accumulate is a chain of dependent steps on few
+// wavefronts.  Sharing a SIMD with three accumulate (or NTT) wavefronts under round-robin issue, such a wavefront
+// gets a quarter of the issue slots and its chain takes 3x as long (r02 device timeline: the G2 bucket reduce 0.9 ms
+// alone, 2.7 ms beside the H accumulate; the H front end 0.44 -> 2.0 ms) -- so these kernels raise their wavefronts'
+// issue priority (s_setprio 3); the throughput kernels stay at 0 and lose a few percent of their slots.
 static constexpr uint32_t kRemClasses = 32;   // remainder tasks are queued by relative length, longest class first
 static constexpr uint32_t kTaskChunk = 64;
 static constexpr uint32_t kLightTasks = 3;    // lower bound of the light/other split (sizes the bucket lists)
@@ -159,7 +190,11 @@ int msm_precompute_g2(const void* in, void* out, uint32_t n, int ndbl);
 // addition of the current one (its load latency hides behind that addition), and a task starts by
 // loading its first point straight into the accumulator (ZZ = ZZZ = 1) and adding the second in the
 // same iteration -- a task of L entries costs L - 1 iterations (1 when L = 1).
-// Exit: the queue counter passes `total` (every wave sees it) and no lane holds or awaits a task.
+// Exit: the queue counter passes `total` (every wave sees it) -- or the wavefront has taken its quota of chunks -- and
+// no lane holds or awaits a task.  chunk_quota = 0xffffffff: persistent wavefronts (a grid that fills the chip once);
+// a small quota: a big grid of short-lived wavefronts, so that wave slots free up all the time and the latency-bound
+// kernels of the other streams get in (r02: behind a persistent grid the H-MSM's front end took 2.6 ms instead of
+// 0.44, the G2 reduce 2.7 instead of 0.9).
 template <class F>
 __global__ __launch_bounds__(64, F::kAccumWavesPerSimd) void msm_accumulate_kernel(const PackedAffine<F>* __restrict__ bases,
                                                             const uint32_t* __restrict__ sorted,
@@ -168,8 +203,9 @@ __global__ __launch_bounds__(64, F::kAccumWavesPerSimd) void msm_accumulate_kern
                                                             const uint4* __restrict__ qdesc,
                                                             uint32_t* __restrict__ queue,
                                                             uint32_t* __restrict__ redo,
-                                                            XYZZ<F>* __restrict__ partial) {
+                                                            XYZZ<F>* __restrict__ partial, uint32_t chunk_quota) {
   const uint32_t total = toff[nbk];
+  uint32_t pulled = 0;                  // wave-uniform: chunks this wavefront has taken (it retires after chunk_quota)
   const uint32_t lane = threadIdx.x;
   const unsigned long long lt_mask = (1ull << lane) - 1;
   constexpr uint32_t kNone = 0xffffffffu;
@@ -207,14 +243,19 @@ __global__ __launch_bounds__(64, F::kAccumWavesPerSimd) void msm_accumulate_kern
     const unsigned long long m = __ballot(want);
     if (m) {
       if (next == chunk_end) {   // wave-uniform: pull the next chunk (`exhausted` is false here: m != 0)
-        uint32_t base = 0;
-        if (lane == 0) base = atomicAdd(queue, kTaskChunk);
-        base = __shfl(base, 0, 64);
-        if (base >= total) {
-          exhausted = true;
+        if (pulled >= chunk_quota) {
+          exhausted = true;   // quota reached: finish what the lanes hold and retire (the slot goes to whoever waits)
         } else {
-          next = base;
-          chunk_end = base + kTaskChunk < total ? base + kTaskChunk : total;
+          uint32_t base = 0;
+          if (lane == 0) base = atomicAdd(queue, kTaskChunk);
+          base = __shfl(base, 0, 64);
+          pulled++;
+          if (base >= total) {
+            exhausted = true;
+          } else {
+            next = base;
+            chunk_end = base + kTaskChunk < total ? base + kTaskChunk : total;
+          }
         }
       }
       if (!exhausted) {
@@ -255,6 +296,7 @@ __global__ __launch_bounds__(64) void msm_redo_kernel(const PackedAffine<F>* __r
                                                       const uint32_t* __restrict__ queue,
                                                       const uint32_t* __restrict__ redo,
                                                       XYZZ<F>* __restrict__ partial) {
+  __builtin_amdgcn_s_setprio(3);   // issue priority over the throughput kernels sharing the SIMD (msm.cuh, kLatencyPrio)
   const uint32_t count = queue[1];
   const uint32_t lane = threadIdx.x;
   for (uint32_t i = blockIdx.x; i < count; i += gridDim.x) {
@@ -307,6 +349,7 @@ __global__ __launch_bounds__(kTailThreads) void msm_combine_light_kernel(const X
                                                                uint32_t* __restrict__ heavy, uint32_t max_heavy,
                                                                uint32_t* __restrict__ medium,
                                                                uint32_t light_max) {
+  __builtin_amdgcn_s_setprio(3);   // issue priority over the throughput kernels sharing the SIMD (msm.cuh, kLatencyPrio)
   const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= nbk) return;
   const uint32_t t0 = toff[b], t1 = toff[b + 1];
@@ -334,6 +377,7 @@ __global__ __launch_bounds__(kTailThreads) void msm_combine_medium_kernel(const 
                                                                 const uint32_t* __restrict__ toff,
                                                                 XYZZ<F>* __restrict__ bsum,
                                                                 const uint32_t* __restrict__ medium, uint32_t max_heavy) {
+  __builtin_amdgcn_s_setprio(3);   // issue priority over the throughput kernels sharing the SIMD (msm.cuh, kLatencyPrio)
   uint32_t count = medium[0];
   if (count > max_heavy) count = max_heavy;
   const uint32_t lane = threadIdx.x & 63u, sub = lane >> 4, l = lane & 15u;
@@ -365,6 +409,7 @@ __global__ __launch_bounds__(kTailThreads) void msm_combine_heavy_kernel(const X
                                                                const uint32_t* __restrict__ toff,
                                                                XYZZ<F>* __restrict__ bsum,
                                                                const uint32_t* __restrict__ heavy, uint32_t max_heavy) {
+  __builtin_amdgcn_s_setprio(3);   // issue priority over the throughput kernels sharing the SIMD (msm.cuh, kLatencyPrio)
   uint32_t count = heavy[0];
   if (count > max_heavy) count = max_heavy;
   const uint32_t lane = threadIdx.x & 63u;
@@ -408,9 +453,16 @@ __global__ __launch_bounds__(kTailThreads) void msm_bucket_reduce_kernel(const X
                                                                uint32_t B, uint32_t nseg, uint32_t rows, uint32_t rps,
                                                                uint32_t W, uint32_t ones, uint32_t salt_bits,
                                                                uint32_t seg_len, XYZZ<F>* __restrict__ seg) {
+  __builtin_amdgcn_s_setprio(3);   // issue priority over the throughput kernels sharing the SIMD (msm.cuh, kLatencyPrio)
   const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
   if (tid >= rows * nseg) return;
   const uint32_t j = tid / nseg, g = tid % nseg;
+  if (j % rps >= W + ones) {                   // dup rows: combined by msm_dup_bits_kernel, not here
+    XYZZ<F> z;
+    x29_set_inf(z);
+    seg[tid] = z;
+    return;
+  }
   const bool plain = ones && (j % rps == W);   // the "ones" pseudo-window: plain sum of its buckets
   // the salted top window: 2^salt_bits consecutive buckets share the weight (index >> salt_bits) + 1, and a
   // segment never straddles two weights (seg_len divides 2^salt_bits)
@@ -437,10 +489,72 @@ __global__ __launch_bounds__(kTailThreads) void msm_bucket_reduce_kernel(const X
   seg[tid] = acc;
 }
 
+// Dup rows, step 1: the qualifying non-empty hash buckets of every section of the lane, compacted into
+// dlist[sl][k] (k < dcount[sl]; order is whatever the atomics give -- the sums commute).
+static __global__ __launch_bounds__(256) void msm_dup_compact_kernel(const uint32_t* __restrict__ toff, uint32_t B, uint32_t rps,
+                                                              uint32_t dup_row0, uint32_t dup_bits, uint32_t sec0,
+                                                              uint32_t nsec_lane, const uint32_t* __restrict__ dup_cnt,
+                                                              const uint32_t* __restrict__ dup_mixed,
+                                                              uint32_t* __restrict__ dcount, uint32_t* __restrict__ dlist) {
+  __builtin_amdgcn_s_setprio(3);   // issue priority over the throughput kernels sharing the SIMD (msm.cuh, kLatencyPrio)
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (nsec_lane << dup_bits)) return;
+  const uint32_t sl = i >> dup_bits, hb = i & ((1u << dup_bits) - 1);
+  const size_t di = ((size_t)(sec0 + sl) << dup_bits) + hb;
+  if (dup_cnt[di] < kDupMin || dup_mixed[di]) return;
+  const uint32_t key = (sl * rps + dup_row0) * B + hb;
+  if (toff[key + 1] == toff[key]) return;
+  const uint32_t k = atomicAdd(&dcount[sl], 1u);
+  dlist[((size_t)sl << dup_bits) + k] = hb;
+}
+
+// Step 2: dseg[(sl * 254 + bit) * nchunk + chunk] = sum of the bucket sums T of list entries [64 chunk, +64) of
+// section sl whose (single) scalar value has bit `bit` set.  One wavefront per (sl, bit, chunk); chunks beyond the
+// list write infinity.  The tree over the chunks is msm_wave_reduce_kernel with 254 * nsec rows.
+template <class F>
+__global__ __launch_bounds__(kTailThreads) void msm_dup_bits_kernel(const XYZZ<F>* __restrict__ partial,
+                                                              const XYZZ<F>* __restrict__ bsum,
+                                                              const uint32_t* __restrict__ toff, uint32_t B,
+                                                              uint32_t rps, uint32_t dup_row0, uint32_t dup_bits,
+                                                              uint32_t sec0, uint32_t nsec_lane, uint32_t nchunk,
+                                                              const uint32_t* __restrict__ dcount,
+                                                              const uint32_t* __restrict__ dlist,
+                                                              const uint32_t* __restrict__ dup_rep,
+                                                              const Fr* __restrict__ scalars,
+                                                              const uint32_t* __restrict__ src,
+                                                              XYZZ<F>* __restrict__ dseg) {
+  __builtin_amdgcn_s_setprio(3);   // issue priority over the throughput kernels sharing the SIMD (msm.cuh, kLatencyPrio)
+  // chunk-major wave order: the waves with work (the first count / 64 chunks of every (section, bit)) are then the
+  // FIRST workgroups of the grid, spread over all CUs.  (Bit-major order put them at a fixed phase of every 64
+  // consecutive workgroups, which the round-robin dispatch maps to the same few CUs: r02, 3.7 ms instead of 0.1.)
+  const uint32_t wid = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), lane = threadIdx.x & 63u;
+  const uint32_t nrow = nsec_lane * kDupBitRows;
+  if (wid >= nrow * nchunk) return;
+  const uint32_t chunk = wid / nrow, row = wid % nrow, bit = row % kDupBitRows, sl = row / kDupBitRows;
+  const uint32_t wave = row * nchunk + chunk;   // output slot: [(sl, bit)][chunk]
+  const uint32_t count = dcount[sl], k = chunk * 64 + lane;
+  XYZZ<F> acc;
+  x29_set_inf(acc);
+  if (chunk * 64 < count) {   // wave-uniform
+    if (k < count) {
+      const uint32_t hb = dlist[((size_t)sl << dup_bits) + k];
+      const Fr v = scalars[src[dup_rep[((size_t)(sec0 + sl) << dup_bits) + hb]]];
+      if ((v.v[bit >> 5] >> (bit & 31)) & 1u)
+        acc = msm_bucket_value<F>(partial, bsum, toff, (sl * rps + dup_row0) * B + hb);
+    }
+    for (int d = 32; d >= 1; d >>= 1) {
+      const XYZZ<F> q = xyzz_shfl_down(acc, d);
+      x29_add(acc, q);
+    }
+  }
+  if (lane == 0) dseg[wave] = acc;
+}
+
 // out[j*nout + blk] = sum of in[j*nin + blk*64 .. +64)
 template <class F>
 __global__ __launch_bounds__(kTailThreads) void msm_wave_reduce_kernel(const XYZZ<F>* __restrict__ in, uint32_t nin,
                                                              XYZZ<F>* __restrict__ out, uint32_t nout) {
+  __builtin_amdgcn_s_setprio(3);   // issue priority over the throughput kernels sharing the SIMD (msm.cuh, kLatencyPrio)
   const uint32_t j = blockIdx.y, blk = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), lane = threadIdx.x & 63u;
   if (blk >= nout) return;   // whole wavefronts leave together
   const uint32_t i = blk * 64 + lane;
@@ -484,6 +598,7 @@ __global__ __launch_bounds__(256) void msm_precompute_kernel(const Affine<FC>* _
 template <class F>
 __global__ __launch_bounds__(64) void msm_to_canon_kernel(const XYZZ<F>* __restrict__ in,
                                                           XYZZ<typename F::CanonOps>* __restrict__ out, uint32_t n) {
+  __builtin_amdgcn_s_setprio(3);   // issue priority over the throughput kernels sharing the SIMD (msm.cuh, kLatencyPrio)
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   XYZZ<typename F::CanonOps> r;
@@ -504,6 +619,9 @@ template <class F>
 int msm_launch_lane_t(const MsmGroup& g, MsmWorkspace* ws, MsmLaneWs& ln, const void* d_bases, hipStream_t st) {
   using PT = XYZZ<F>;
   using CPT = XYZZ<typename F::CanonOps>;
+  using FT = typename F::Tail;   // same element layout; products called instead of inlined where that pays (G2)
+  using TPT = XYZZ<FT>;
+  static_assert(sizeof(TPT) == sizeof(PT), "tail ops must share the point layout");
   static const bool trace = getenv("G16_TRACE_HOST") != nullptr;
   auto mark = [&](int k) {
     if (!trace) return;
@@ -521,50 +639,94 @@ int msm_launch_lane_t(const MsmGroup& g, MsmWorkspace* ws, MsmLaneWs& ln, const 
   const uint32_t full_occ = (uint32_t)F::kAccumWavesPerSimd;
   const uint32_t occ = (ln.waves_per_simd && ln.waves_per_simd < full_occ) ? ln.waves_per_simd : full_occ;
   uint64_t waves = (uint64_t)256 * 4 * occ;
-  if (waves > (ln.max_tasks + kTaskChunk - 1) / kTaskChunk) waves = (ln.max_tasks + kTaskChunk - 1) / kTaskChunk;
+  const uint64_t max_chunks = (ln.max_tasks + kTaskChunk - 1) / kTaskChunk;
+  uint32_t quota = 0xffffffffu;
+  if (ln.chunk_quota) {   // short-lived wavefronts: enough of them to drain the queue, quota chunks each
+    quota = ln.chunk_quota;
+    waves = (max_chunks + quota - 1) / quota + 64;
+  }
+  if (waves > max_chunks) waves = max_chunks;
   if (waves == 0) waves = 1;
   G16_HIP(hipMemsetAsync(ln.d_queue, 0, 8, st));
   if (ln.gate) G16_HIP(hipStreamWaitEvent(st, ln.gate, 0));
   G16_HIP(hipEventRecord(ln.ev0, st));
   msm_accumulate_kernel<F><<<(unsigned)waves, 64, 0, st>>>((const PackedAffine<F>*)d_bases, ws->d_sorted, ln.d_toff, nbk,
                                                             ln.point_base, ln.d_qdesc, ln.d_queue, ln.d_redo,
-                                                            (PT*)ln.d_partial);
+                                                            (PT*)ln.d_partial, quota);
   G16_HIP(hipEventRecord(ln.ev1, st));
   msm_redo_kernel<F><<<64, 64, 0, st>>>((const PackedAffine<F>*)d_bases, ws->d_sorted, ln.point_base, ln.d_task_desc,
                                         ln.d_queue, ln.d_redo, (PT*)ln.d_partial);
   G16_HIP(hipMemsetAsync(ln.d_heavy, 0, 4, st));
   G16_HIP(hipMemsetAsync(ln.d_medium, 0, 4, st));
-  msm_combine_light_kernel<F><<<(nbk + kTailThreads - 1) / kTailThreads, kTailThreads, 0, st>>>((const PT*)ln.d_partial, ln.d_toff, nbk,
-                                                              (PT*)ln.d_bsum, ln.d_heavy, ln.max_heavy, ln.d_medium,
+  msm_combine_light_kernel<FT><<<(nbk + kTailThreads - 1) / kTailThreads, kTailThreads, 0, st>>>((const TPT*)ln.d_partial, ln.d_toff, nbk,
+                                                              (TPT*)ln.d_bsum, ln.d_heavy, ln.max_heavy, ln.d_medium,
                                                               msm_light_max(ln));
-  msm_combine_medium_kernel<F><<<1024, kTailThreads, 0, st>>>((const PT*)ln.d_partial, ln.d_toff, (PT*)ln.d_bsum, ln.d_medium,
+  msm_combine_medium_kernel<FT><<<1024, kTailThreads, 0, st>>>((const TPT*)ln.d_partial, ln.d_toff, (TPT*)ln.d_bsum, ln.d_medium,
                                                               ln.max_heavy);
   // one wavefront per heavy bucket, all at once (a real NZCP witness puts thousands of entries into the buckets of
   // its byte-valued scalars and of the narrow top window: r02, 1 024 looping wavefronts took 3 rounds)
-  msm_combine_heavy_kernel<F><<<2048, kTailThreads, 0, st>>>((const PT*)ln.d_partial, ln.d_toff, (PT*)ln.d_bsum,
+  msm_combine_heavy_kernel<FT><<<2048, kTailThreads, 0, st>>>((const TPT*)ln.d_partial, ln.d_toff, (TPT*)ln.d_bsum,
                                                    ln.d_heavy, ln.max_heavy);
   mark(1);
-  msm_bucket_reduce_kernel<F><<<(ln.rows * nseg + kTailThreads - 1) / kTailThreads, kTailThreads, 0, st>>>((const PT*)ln.d_partial, (const PT*)ln.d_bsum,
+  uint32_t nout_pts = ln.rows;
+  if (g.dup_rows) {
+    // beside the reduce + tree of the digit rows (both are chains of sequential additions on few wavefronts)
+    hipStream_t sd = ln.st_dup ? ln.st_dup : st;
+    if (sd != st) {
+      G16_HIP(hipEventRecord(ln.ev_dup_fork, st));
+      G16_HIP(hipStreamWaitEvent(sd, ln.ev_dup_fork, 0));
+    }
+    // dup rows: bit-position sums of the repeated-value bucket sums (bucket keys are lane-local: section sl of the
+    // lane starts at row sl * rps)
+    // at most kDupChunks * 64 distinct repeated values per section take this path (more are simply left out of
+    // the list... they cannot be: every qualifying bucket must be summed) -> the chunk count covers all buckets
+    const uint32_t nchunk = (1u << g.dup_bits) >> 6, drows = ln.nsec_lane * kDupBitRows;
+    const uint32_t waves_d = drows * nchunk;
+    const uint32_t sec0 = ln.key_lo / (g.rps * g.B), dup_row0 = (uint32_t)g.W + (g.ones ? 1u : 0u);
+    G16_HIP(hipMemsetAsync(ln.d_dcount, 0, 16, sd));
+    msm_dup_compact_kernel<<<((ln.nsec_lane << g.dup_bits) + 255) / 256, 256, 0, sd>>>(
+        ln.d_toff, g.B, g.rps, dup_row0, g.dup_bits, sec0, ln.nsec_lane, ws->d_dup_cnt, ws->d_dup_mixed, ln.d_dcount, ln.d_dlist);
+    msm_dup_bits_kernel<FT><<<(waves_d + 3) / 4, kTailThreads, 0, sd>>>(
+        (const TPT*)ln.d_partial, (const TPT*)ln.d_bsum, ln.d_toff, g.B, g.rps, dup_row0, g.dup_bits, sec0, ln.nsec_lane, nchunk,
+        ln.d_dcount, ln.d_dlist, ws->d_dup_rep, ws->d_scalars, g.d_src, (TPT*)ln.d_dseg);
+    TPT* dcur = (TPT*)ln.d_dseg;
+    uint32_t dcnt = nchunk;
+    TPT* dbufs[2] = {(TPT*)ln.d_dred, (TPT*)ln.d_dred + (size_t)drows * ((nchunk + 63) / 64)};
+    int dflip = 0;
+    while (dcnt > 1) {
+      const uint32_t nout = (dcnt + 63) / 64;
+      msm_wave_reduce_kernel<FT><<<dim3((nout + 3) / 4, drows), kTailThreads, 0, sd>>>(dcur, dcnt, dbufs[dflip], nout);
+      dcur = dbufs[dflip];
+      dflip ^= 1;
+      dcnt = nout;
+    }
+    msm_to_canon_kernel<F><<<(drows + 63) / 64, 64, 0, sd>>>((const PT*)dcur, (CPT*)ln.d_canon + ln.rows, drows);
+    G16_HIP(hipGetLastError());
+    nout_pts += drows;
+    if (sd != st) G16_HIP(hipEventRecord(ln.ev_dup_join, sd));
+  }
+  msm_bucket_reduce_kernel<FT><<<(ln.rows * nseg + kTailThreads - 1) / kTailThreads, kTailThreads, 0, st>>>((const TPT*)ln.d_partial, (const TPT*)ln.d_bsum,
                                                                         ln.d_toff, g.B, nseg, ln.rows, g.rps,
                                                                         (uint32_t)g.W, g.ones ? 1u : 0u, g.salt_bits, seg_len,
-                                                                        (PT*)ln.d_seg);
+                                                                        (TPT*)ln.d_seg);
   mark(2);
   // tree: d_seg (nseg per row) -> ... -> 1 per row, ping-pong between d_red halves
-  PT* cur = (PT*)ln.d_seg;
+  TPT* cur = (TPT*)ln.d_seg;
   uint32_t cnt = nseg;
-  PT* bufs[2] = {(PT*)ln.d_red, (PT*)ln.d_red + (size_t)ln.rows * ((nseg + 63) / 64)};
+  TPT* bufs[2] = {(TPT*)ln.d_red, (TPT*)ln.d_red + (size_t)ln.rows * ((nseg + 63) / 64)};
   int flip = 0;
   while (cnt > 1) {
     const uint32_t nout = (cnt + 63) / 64;
-    msm_wave_reduce_kernel<F><<<dim3((nout + 3) / 4, ln.rows), kTailThreads, 0, st>>>(cur, cnt, bufs[flip], nout);
+    msm_wave_reduce_kernel<FT><<<dim3((nout + 3) / 4, ln.rows), kTailThreads, 0, st>>>(cur, cnt, bufs[flip], nout);
     cur = bufs[flip];
     flip ^= 1;
     cnt = nout;
   }
   G16_HIP(hipGetLastError());
-  msm_to_canon_kernel<F><<<(ln.rows + 63) / 64, 64, 0, st>>>(cur, (CPT*)ln.d_canon, ln.rows);
+  msm_to_canon_kernel<F><<<(ln.rows + 63) / 64, 64, 0, st>>>((const PT*)cur, (CPT*)ln.d_canon, ln.rows);
   G16_HIP(hipGetLastError());
-  G16_HIP(hipMemcpyAsync(ln.h_pinned, ln.d_canon, (size_t)ln.rows * sizeof(CPT), hipMemcpyDeviceToHost, st));
+  if (g.dup_rows && ln.st_dup) G16_HIP(hipStreamWaitEvent(st, ln.ev_dup_join, 0));
+  G16_HIP(hipMemcpyAsync(ln.h_pinned, ln.d_canon, (size_t)nout_pts * sizeof(CPT), hipMemcpyDeviceToHost, st));
   mark(3);
   G16_HIP(hipEventRecord(ln.ev_done, st));
   return G16_OK;

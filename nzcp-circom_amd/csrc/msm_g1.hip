@@ -35,6 +35,45 @@ __device__ __forceinline__ bool msm_load_scalar(const Fr* __restrict__ scalars, 
   return one;
 }
 
+// Repeated-value detection (MsmGroup::dup_rows), two passes over the points of a group:
+//   count: every scalar other than 0 and 1 is hashed to a bucket of its section; the bucket counts it and keeps one
+//          representative point;
+//   check: a point whose scalar differs from its bucket's representative marks the bucket mixed (exact 256-bit
+//          comparison: a qualifying bucket holds ONE value).
+// msm_bin_pass_kernel then routes the points of buckets with >= kDupMin equal scalars to the dup rows.
+__device__ __forceinline__ bool msm_scalar_is_01(const Fr& x) {
+  uint32_t hi = 0;
+#pragma unroll
+  for (int k = 1; k < 8; k++) hi |= x.v[k];
+  return hi == 0 && x.v[0] <= 1u;
+}
+template <int CHECK>
+static __global__ __launch_bounds__(256) void msm_dup_scan_kernel(const Fr* __restrict__ scalars,
+                                                           const uint32_t* __restrict__ src, MsmPlan pl,
+                                                           uint32_t* __restrict__ dup_cnt, uint32_t* __restrict__ dup_rep,
+                                                           uint32_t* __restrict__ dup_mixed) {
+  __builtin_amdgcn_s_setprio(3);   // issue priority over the throughput kernels sharing the SIMD (msm.cuh, kLatencyPrio)
+  const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= pl.n) return;
+  uint32_t s = 0;
+  if (pl.nsec > 1 && g >= pl.sec_begin[1]) s = 1;
+  if (pl.nsec > 2 && g >= pl.sec_begin[2]) s = 2;
+  const Fr x = scalars[src[g]];
+  if (msm_scalar_is_01(x)) return;
+  const size_t di = ((size_t)s << pl.dup_bits) + msm_dup_hash(x.v, pl.dup_bits);
+  if (!CHECK) {
+    atomicAdd(&dup_cnt[di], 1u);
+    if (dup_rep[di] == 0xffffffffu) atomicCAS(&dup_rep[di], 0xffffffffu, g);
+  } else {
+    if (dup_cnt[di] < kDupMin || dup_mixed[di]) return;
+    const Fr y = scalars[src[dup_rep[di]]];
+    uint32_t diff = 0;
+#pragma unroll
+    for (int k = 0; k < 8; k++) diff |= x.v[k] ^ y.v[k];
+    if (diff) dup_mixed[di] = 1u;
+  }
+}
+
 // Pass 0 (MODE 0) counts, pass 1 (MODE 1) scatters the bucket entries of a chunk of points into (row, bin) runs.
 // A workgroup owns points [blockIdx.x * per, +per); its LDS holds one counter / cursor per (row, bin).  Signed
 // digit j of point i (section s) becomes the entry (table index | sign << 31, low bucket bits) in row
@@ -51,7 +90,10 @@ static __global__ __launch_bounds__(kBinThreads) void msm_bin_pass_kernel(const 
                                                             const uint32_t* __restrict__ src, MsmPlan pl, U256 K,
                                                             uint32_t per, uint32_t chunks, uint32_t* __restrict__ hist,
                                                             const uint32_t* __restrict__ bin_start,
+                                                            const uint32_t* __restrict__ dup_cnt,
+                                                            const uint32_t* __restrict__ dup_mixed,
                                                             uint2* __restrict__ tmp) {
+  __builtin_amdgcn_s_setprio(3);   // issue priority over the throughput kernels sharing the SIMD (msm.cuh, kLatencyPrio)
   extern __shared__ uint32_t lds[];
   const uint32_t nrb = pl.rows * pl.bins;
   for (uint32_t b = threadIdx.x; b < nrb; b += kBinThreads)
@@ -94,6 +136,21 @@ static __global__ __launch_bounds__(kBinThreads) void msm_bin_pass_kernel(const 
       }
     }
     if (!live || (one && pl.ones)) continue;
+    if (pl.dup_rows) {
+      // a value shared by >= kDupMin points of the section: ONE entry in the section's dup rows
+      const Fr x = scalars[src[g]];
+      if (!msm_scalar_is_01(x)) {
+        const uint32_t hb = msm_dup_hash(x.v, pl.dup_bits);
+        const size_t di = ((size_t)s << pl.dup_bits) + hb;
+        if (dup_cnt[di] >= kDupMin && !dup_mixed[di]) {
+          const uint32_t row = row0 + pl.W + pl.ones + hb / pl.B, bucket = hb & (pl.B - 1);
+          const uint32_t rb = row * pl.bins + (bucket >> pl.low_bits);
+          const uint32_t pos = atomicAdd(&lds[rb], 1u);
+          if (MODE) tmp[pos] = make_uint2(g, bucket & lowmask);
+          continue;
+        }
+      }
+    }
     uint32_t j = threadIdx.x % Ws;
     for (uint32_t t = 0; t < Ws; t++) {
       const uint32_t e = msm_extract(sc, (int)(j * (uint32_t)pl.c), pl.c);
@@ -121,6 +178,7 @@ static __global__ __launch_bounds__(kBinThreads) void msm_bin_pass_kernel(const 
 // relative to the bin's start), bin_cnt[rb] = the bin's total.
 static __global__ __launch_bounds__(64) void msm_bin_chunkscan_kernel(uint32_t* __restrict__ hist, uint32_t chunks,
                                                                uint32_t* __restrict__ bin_cnt) {
+  __builtin_amdgcn_s_setprio(3);   // issue priority over the throughput kernels sharing the SIMD (msm.cuh, kLatencyPrio)
   const uint32_t rb = blockIdx.x, lane = threadIdx.x;
   uint32_t* __restrict__ h = hist + (size_t)rb * chunks;
   const uint32_t per = (chunks + 63) / 64;
@@ -143,6 +201,7 @@ static __global__ __launch_bounds__(64) void msm_bin_chunkscan_kernel(uint32_t* 
 // exclusive scan of bin_cnt[0, nrb) by one workgroup -> bin_start[0, nrb], bin_start[nrb] = total
 static __global__ __launch_bounds__(1024) void msm_bin_scan_kernel(const uint32_t* __restrict__ bin_cnt, uint32_t nrb,
                                                             uint32_t* __restrict__ bin_start) {
+  __builtin_amdgcn_s_setprio(3);   // issue priority over the throughput kernels sharing the SIMD (msm.cuh, kLatencyPrio)
   __shared__ uint32_t sh[1024];
   const uint32_t tid = threadIdx.x;
   const uint32_t per = (nrb + 1023) / 1024;
@@ -174,6 +233,7 @@ static constexpr uint32_t kMaxLowBits = 12;
 static __global__ __launch_bounds__(256) void msm_bin_sort_kernel(const uint2* __restrict__ tmp,
                                                            const uint32_t* __restrict__ bin_start, MsmPlan pl,
                                                            uint32_t* __restrict__ cnt, uint32_t* __restrict__ sorted) {
+  __builtin_amdgcn_s_setprio(3);   // issue priority over the throughput kernels sharing the SIMD (msm.cuh, kLatencyPrio)
   __shared__ uint32_t c[1u << kMaxLowBits];
   __shared__ uint32_t part[256];
   const uint32_t rb = blockIdx.x, tid = threadIdx.x;
@@ -243,6 +303,7 @@ static __global__ __launch_bounds__(256) void msm_scan_tiles_kernel(const uint32
                                                              uint32_t tl, uint32_t* __restrict__ tile_a,
                                                              uint32_t* __restrict__ tile_b,
                                                              uint32_t* __restrict__ tile_c) {
+  __builtin_amdgcn_s_setprio(3);   // issue priority over the throughput kernels sharing the SIMD (msm.cuh, kLatencyPrio)
   __shared__ uint32_t sh_a[256], sh_b[256], sh_c[256];
   const uint32_t tid = threadIdx.x, base = blockIdx.x * kScanTile + tid * 8;
   uint32_t sa = 0, sb = 0, sc = 0;
@@ -270,6 +331,7 @@ static __global__ __launch_bounds__(1024) void msm_scan_top_kernel(uint32_t* __r
                                                             uint32_t* __restrict__ total_a,
                                                             uint32_t* __restrict__ total_b,
                                                             uint32_t* __restrict__ total_c) {
+  __builtin_amdgcn_s_setprio(3);   // issue priority over the throughput kernels sharing the SIMD (msm.cuh, kLatencyPrio)
   __shared__ uint32_t sh_a[1024], sh_b[1024], sh_c[1024];
   const uint32_t tid = threadIdx.x;
   const uint32_t chunk = (ntiles + 1023) / 1024;
@@ -302,6 +364,7 @@ static __global__ __launch_bounds__(256) void msm_scan_apply_kernel(const uint32
                                                              uint32_t* __restrict__ off,
                                                              uint32_t* __restrict__ toff,
                                                              uint32_t* __restrict__ foff) {
+  __builtin_amdgcn_s_setprio(3);   // issue priority over the throughput kernels sharing the SIMD (msm.cuh, kLatencyPrio)
   __shared__ uint32_t sh_a[256], sh_b[256], sh_c[256];
   const uint32_t tid = threadIdx.x, base = blockIdx.x * kScanTile + tid * 8;
   uint32_t v[8], sa = 0, sb = 0, sc = 0;
@@ -351,6 +414,7 @@ __device__ __forceinline__ uint32_t msm_rem_class(uint32_t len, uint32_t task_le
 // class_total[c] = number of remainder tasks (cnt % task_len != 0) of relative-length class c
 static __global__ __launch_bounds__(256) void msm_rem_count_kernel(const uint32_t* __restrict__ cnt, uint32_t nbk,
                                                             uint32_t tl, uint32_t* __restrict__ class_total) {
+  __builtin_amdgcn_s_setprio(3);   // issue priority over the throughput kernels sharing the SIMD (msm.cuh, kLatencyPrio)
   __shared__ uint32_t h[kRemClasses];
   if (threadIdx.x < kRemClasses) h[threadIdx.x] = 0;
   __syncthreads();
@@ -370,6 +434,7 @@ static __global__ __launch_bounds__(256) void msm_task_fill_kernel(const uint32_
                                                             uint2* __restrict__ task_desc, uint4* __restrict__ qdesc,
                                                             const uint32_t* __restrict__ class_total,
                                                             uint32_t* __restrict__ class_cursor) {
+  __builtin_amdgcn_s_setprio(3);   // issue priority over the throughput kernels sharing the SIMD (msm.cuh, kLatencyPrio)
   // remainders: after all the full tasks, by relative-length class (longest first) so that the lanes of a
   // wavefront hold remainders of (nearly) equal length; inside a class the order is whatever the atomics give
   __shared__ uint32_t h[kRemClasses], base[kRemClasses];
@@ -430,6 +495,8 @@ static MsmPlan msm_plan_of(const MsmGroup& g) {
   pl.rows = g.rows;
   pl.ones = g.ones ? 1u : 0u;
   pl.salt_bits = g.salt_bits;
+  pl.dup_rows = g.dup_rows;
+  pl.dup_bits = g.dup_bits;
   return pl;
 }
 
@@ -588,7 +655,16 @@ int msm_group_create(MsmGroup& g, const MsmSectionIn* secs, int nsec, const MsmC
     const bool salt_off = getenv("G16_NO_SALT") && atoi(getenv("G16_NO_SALT"));
     if (g.pf == 1 && top_bits >= 1 && (g.c - 1) - top_bits >= 4 && !salt_off) g.salt_bits = (uint32_t)((g.c - 1) - top_bits);
   }
-  g.rps = (uint32_t)g.W + (g.ones ? 1u : 0u);
+  // dup rows (see MsmGroup::dup_rows): witness groups with at least 1024 buckets per row; 2^14 hash buckets per section
+  {
+    const bool dup_off = getenv("G16_NO_DUP") && atoi(getenv("G16_NO_DUP"));
+    if (!cfg.dense && g.pf == 1 && g.B >= 1024 && !dup_off) {
+      g.dup_rows = g.B >= 16384 ? 1u : 16384u / g.B;
+      g.dup_bits = 0;
+      while ((1u << g.dup_bits) < g.dup_rows * g.B) g.dup_bits++;
+    }
+  }
+  g.rps = (uint32_t)g.W + (g.ones ? 1u : 0u) + g.dup_rows;
   g.rows = (uint32_t)nsec * g.rps;
   // two-level sort: bucket = bin << low_bits | low; 8 low bits unless that leaves too many (row, bin) counters
   // for the LDS of the binning passes (<= 12288)
@@ -693,7 +769,24 @@ static int lane_create(MsmLaneWs& ln, const MsmGroup& g, int curve, uint32_t key
   G16_HIP(hipMalloc(&ln.d_medium, ((size_t)ln.max_heavy + 2) * 4));
   G16_HIP(hipMalloc(&ln.d_seg, (size_t)ln.rows * nseg * pb + 256));
   G16_HIP(hipMalloc(&ln.d_red, 2 * (size_t)ln.rows * ((nseg + 63) / 64) * pb + 256));
-  ln.out_bytes = (size_t)ln.rows * cpb;
+  ln.nsec_lane = ln.rows / g.rps;
+  size_t out_pts = ln.rows;
+  if (g.dup_rows) {
+    const size_t nchunk = ((size_t)1 << g.dup_bits) >> 6, drows = (size_t)ln.nsec_lane * kDupBitRows;
+    out_pts += drows;
+    G16_HIP(hipMalloc(&ln.d_dseg, drows * nchunk * pb + 256));
+    G16_HIP(hipMalloc(&ln.d_dred, 2 * drows * ((nchunk + 63) / 64) * pb + 256));
+    G16_HIP(hipMalloc(&ln.d_dcount, 64));
+    if (curve == 2) {   // G2: its own stream beside the bucket reduce (G1's dup stage is short: it stays on the lane's
+      int plo = 0, phi = 0;   // stream -- hardware queues are scarce, see prover.cpp create_impl)
+      G16_HIP(hipDeviceGetStreamPriorityRange(&plo, &phi));
+      G16_HIP(hipStreamCreateWithPriority(&ln.st_dup, hipStreamNonBlocking, phi));
+    }
+    G16_HIP(hipEventCreateWithFlags(&ln.ev_dup_fork, hipEventDisableTiming));
+    G16_HIP(hipEventCreateWithFlags(&ln.ev_dup_join, hipEventDisableTiming));
+    G16_HIP(hipMalloc(&ln.d_dlist, ((size_t)ln.nsec_lane << g.dup_bits) * 4 + 64));
+  }
+  ln.out_bytes = out_pts * cpb;
   G16_HIP(hipHostMalloc((void**)&ln.h_pinned, ln.out_bytes + 256));
   G16_HIP(hipMalloc(&ln.d_canon, ln.out_bytes + 256));
   G16_HIP(hipEventCreate(&ln.ev0));
@@ -704,11 +797,14 @@ static int lane_create(MsmLaneWs& ln, const MsmGroup& g, int curve, uint32_t key
 
 static void lane_destroy(MsmLaneWs& ln) {
   void* ptrs[] = {ln.d_task_desc, ln.d_qdesc, ln.d_class, ln.d_queue, ln.d_redo, ln.d_partial, ln.d_bsum, ln.d_heavy, ln.d_medium,
-                  ln.d_seg, ln.d_red, ln.d_canon, ln.d_off, ln.d_toff, ln.d_foff, ln.d_tile_a, ln.d_tile_b, ln.d_tile_c};
+                  ln.d_seg, ln.d_red, ln.d_canon, ln.d_off, ln.d_toff, ln.d_foff, ln.d_tile_a, ln.d_tile_b, ln.d_tile_c,
+                  ln.d_dseg, ln.d_dred, ln.d_dcount, ln.d_dlist};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   if (ln.h_pinned) (void)hipHostFree(ln.h_pinned);
-  hipEvent_t evs[] = {ln.ev0, ln.ev1, ln.ev_done, ln.trace_ev[0], ln.trace_ev[1], ln.trace_ev[2], ln.trace_ev[3]};
+  if (ln.st_dup) (void)hipStreamDestroy(ln.st_dup);
+  hipEvent_t evs[] = {ln.ev0, ln.ev1, ln.ev_done, ln.trace_ev[0], ln.trace_ev[1], ln.trace_ev[2], ln.trace_ev[3],
+                      ln.ev_dup_fork, ln.ev_dup_join};
   for (hipEvent_t e : evs)
     if (e) (void)hipEventDestroy(e);
   ln = MsmLaneWs();
@@ -726,6 +822,12 @@ int msm_workspace_create(MsmWorkspace** out, const MsmGroup& g) {
   G16_HIP(hipMalloc(&ws->d_tmp, (g.max_entries + 4) * sizeof(uint2)));
   G16_HIP(hipMalloc(&ws->d_sorted, (g.max_entries + 4) * 4));
   G16_HIP(hipMalloc(&ws->d_cnt, ((size_t)ws->nb + 4) * 4));
+  if (g.dup_rows) {
+    const size_t nd = (size_t)g.nsec << g.dup_bits;
+    G16_HIP(hipMalloc(&ws->d_dup_cnt, nd * 4));
+    G16_HIP(hipMalloc(&ws->d_dup_rep, nd * 4));
+    G16_HIP(hipMalloc(&ws->d_dup_mixed, nd * 4));
+  }
   G16_HIP(hipEventCreate(&ws->ev_sorted));
   int rc = G16_OK;
   const uint32_t div = g.dense ? 1 : 3;   // effective (full-width) share of the scalars
@@ -740,7 +842,8 @@ int msm_workspace_create(MsmWorkspace** out, const MsmGroup& g) {
 
 void msm_workspace_destroy(MsmWorkspace* ws) {
   if (!ws) return;
-  void* ptrs[] = {ws->d_hist, ws->d_bin_cnt, ws->d_bin_start, ws->d_tmp, ws->d_sorted, ws->d_cnt};
+  void* ptrs[] = {ws->d_hist, ws->d_bin_cnt, ws->d_bin_start, ws->d_tmp, ws->d_sorted, ws->d_cnt,
+                  ws->d_dup_cnt, ws->d_dup_rep, ws->d_dup_mixed};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   for (auto& ln : ws->lane) lane_destroy(ln);
@@ -762,14 +865,23 @@ int msm_front_end(const MsmGroup& g, MsmWorkspace* ws, const Fr* d_scalars, hipS
     (void)hipEventRecord(ws->trace_ev[k], st);
   };
   const size_t lds = (size_t)nrb * 4;
+  ws->d_scalars = d_scalars;
+  if (g.dup_rows) {
+    const size_t nd = (size_t)g.nsec << g.dup_bits;
+    G16_HIP(hipMemsetAsync(ws->d_dup_cnt, 0, nd * 4, st));
+    G16_HIP(hipMemsetAsync(ws->d_dup_rep, 0xff, nd * 4, st));
+    G16_HIP(hipMemsetAsync(ws->d_dup_mixed, 0, nd * 4, st));
+    msm_dup_scan_kernel<0><<<(g.n + 255) / 256, 256, 0, st>>>(d_scalars, g.d_src, pl, ws->d_dup_cnt, ws->d_dup_rep, ws->d_dup_mixed);
+    msm_dup_scan_kernel<1><<<(g.n + 255) / 256, 256, 0, st>>>(d_scalars, g.d_src, pl, ws->d_dup_cnt, ws->d_dup_rep, ws->d_dup_mixed);
+  }
   msm_bin_pass_kernel<0><<<g.chunks, kBinThreads, lds, st>>>(d_scalars, g.d_src, pl, K, g.per, g.chunks, ws->d_hist, nullptr,
-                                                             nullptr);
+                                                             ws->d_dup_cnt, ws->d_dup_mixed, nullptr);
   mark(0);
   msm_bin_chunkscan_kernel<<<nrb, 64, 0, st>>>(ws->d_hist, g.chunks, ws->d_bin_cnt);
   msm_bin_scan_kernel<<<1, 1024, 0, st>>>(ws->d_bin_cnt, nrb, ws->d_bin_start);
   mark(1);
   msm_bin_pass_kernel<1><<<g.chunks, kBinThreads, lds, st>>>(d_scalars, g.d_src, pl, K, g.per, g.chunks, ws->d_hist,
-                                                             ws->d_bin_start, ws->d_tmp);
+                                                             ws->d_bin_start, ws->d_dup_cnt, ws->d_dup_mixed, ws->d_tmp);
   mark(2);
   msm_bin_sort_kernel<<<nrb, 256, 0, st>>>(ws->d_tmp, ws->d_bin_start, pl, ws->d_cnt, ws->d_sorted);
   mark(3);
@@ -832,7 +944,13 @@ int msm_launch(const MsmGroup& g, MsmWorkspace* ws, const Fr* d_scalars, hipStre
 }
 
 hipEvent_t msm_event(MsmWorkspace* ws, int which) {
-  return which == 0 ? ws->ev_sorted : which == 1 ? ws->lane[0].ev0 : ws->lane[0].ev1;
+  switch (which) {
+    case 0: return ws->ev_sorted;
+    case 1: return ws->lane[0].ev0;
+    case 2: return ws->lane[0].ev1;
+    case 3: return ws->lane[0].active ? ws->lane[0].ev_done : nullptr;
+    default: return ws->lane[1].active ? ws->lane[1].ev_done : nullptr;
+  }
 }
 
 int msm_collect(const MsmGroup& g, MsmWorkspace* ws, MsmResult* out) {
@@ -844,12 +962,21 @@ int msm_collect(const MsmGroup& g, MsmWorkspace* ws, MsmResult* out) {
     if (!ln.active) continue;
     G16_HIP(hipEventSynchronize(ln.ev_done));
     (void)hipEventElapsedTime(&ln.last_accum_ms, ln.ev0, ln.ev1);
+    if (g.dup_rows && getenv("G16_DEBUG_DUP")) {
+      uint32_t dc[4] = {0, 0, 0, 0};
+      (void)hipMemcpy(dc, ln.d_dcount, 16, hipMemcpyDeviceToHost);
+      fprintf(stderr, "[g16 dup] lane %d: repeated-value buckets per section: %u %u %u\n", l, dc[0], dc[1], dc[2]);
+    }
     if (l == 0) {
       const G1XYZZ* rows = reinterpret_cast<const G1XYZZ*>(ln.h_pinned);
-      for (int s = 0; s < g.nsec; s++) msm_combine_windows<FqOps>(out->g1[s], rows + (size_t)s * g.rps, g.W, g.c, g.ones);
+      for (int s = 0; s < g.nsec; s++) {
+        msm_combine_windows<FqOps>(out->g1[s], rows + (size_t)s * g.rps, g.W, g.c, g.ones);
+        if (g.dup_rows) msm_add_bit_sums<FqOps>(out->g1[s], rows + ln.rows + (size_t)s * kDupBitRows);
+      }
     } else {
       const G2XYZZ* rows = reinterpret_cast<const G2XYZZ*>(ln.h_pinned);
       msm_combine_windows<Fq2Ops>(out->g2, rows, g.W, g.c, g.ones);
+      if (g.dup_rows) msm_add_bit_sums<Fq2Ops>(out->g2, rows + ln.rows);
     }
   }
   return G16_OK;
@@ -859,6 +986,10 @@ float msm_last_accum_ms(const MsmWorkspace* ws, int lane) { return ws->lane[lane
 void msm_set_waves(MsmWorkspace* ws, uint32_t waves_g1, uint32_t waves_g2) {
   ws->lane[0].waves_per_simd = waves_g1;
   ws->lane[1].waves_per_simd = waves_g2;
+}
+void msm_set_quota(MsmWorkspace* ws, uint32_t quota_g1, uint32_t quota_g2) {
+  ws->lane[0].chunk_quota = quota_g1;
+  ws->lane[1].chunk_quota = quota_g2;
 }
 // which: 0..3 front-end marks (lane ignored), 4/5 accumulate start/end, 6..9 the lane's marks
 float msm_event_offset_ms(MsmWorkspace* ws, hipEvent_t base, int lane, int which) {

@@ -305,9 +305,23 @@ static int create_impl(const uint8_t* zkey, size_t len, const g16_opts* opts, g1
   // main stream (QAP -> NTT -> H-MSM, the critical path) at high priority, witness MSM streams low
   int prio_lo = 0, prio_hi = 0;
   G16_HIP(hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
+  if (getenv("G16_FLAT_PRIO") && atoi(getenv("G16_FLAT_PRIO"))) prio_lo = prio_hi;   // sweeps: every stream alike
+  // HIP multiplexes streams onto a few hardware queues (4 per priority level by default, least-used first): two
+  // streams on one queue run FIFO, whatever their events say.  r02 found the witness G2 lane on the main stream's
+  // queue (its 0.9 ms bucket reduce "took" 2.7 ms behind the H-MSM's kernels), so context 0 -- the single-proof path
+  // -- creates its streams first and back to back: main, G2 lane and the G2 lane's dup-row stream (high priority:
+  // three distinct queues), witness front end + G1 lane (low priority: its own pool).
+  const bool serial_mode = getenv("G16_SERIAL_MSM") && atoi(getenv("G16_SERIAL_MSM"));
   for (auto& c : P->ctx) {
     G16_HIP(hipStreamCreateWithPriority(&c.st, hipStreamNonBlocking, prio_hi));
+    if (serial_mode) {
+      c.wst = c.wst2 = c.st;
+    } else {
+      G16_HIP(hipStreamCreateWithPriority(&c.wst2, hipStreamNonBlocking, prio_hi));
+      G16_HIP(hipStreamCreateWithPriority(&c.wst, hipStreamNonBlocking, prio_lo));
+    }
     for (auto& e : c.ev) G16_HIP(hipEventCreate(&e));
+    break;   // context 1 (batch pipelining) after context 0's workspaces, below
   }
   P->st = P->ctx[0].st;
   if ((rc = build_csr(P, s4))) return rc;
@@ -362,18 +376,22 @@ static int create_impl(const uint8_t* zkey, size_t len, const g16_opts* opts, g1
   }
   // G16_SERIAL_MSM=1 (profiling aid): every MSM on the main stream, so kernel times are standalone
   const bool serial = getenv("G16_SERIAL_MSM") && atoi(getenv("G16_SERIAL_MSM"));
-  for (auto& c : P->ctx) {
+  for (int ci = 0; ci < g16_prover::kCtx; ci++) {
+    auto& c = P->ctx[ci];
+    if (ci > 0) {   // later contexts: same streams, created after context 0 has its queues
+      G16_HIP(hipStreamCreateWithPriority(&c.st, hipStreamNonBlocking, prio_hi));
+      if (serial) {
+        c.wst = c.wst2 = c.st;
+      } else {
+        G16_HIP(hipStreamCreateWithPriority(&c.wst2, hipStreamNonBlocking, prio_hi));
+        G16_HIP(hipStreamCreateWithPriority(&c.wst, hipStreamNonBlocking, prio_lo));
+      }
+      for (auto& e : c.ev) G16_HIP(hipEventCreate(&e));
+    }
     for (int i = 0; i < 3; i++) {
-      if ((rc = msm_workspace_create(&c.ws[i], P->grp[i]))) return rc;
+      if ((rc = msm_workspace_create(&c.ws[i], P->grp[i]))) return rc;   // (creates the G2 lane's dup-row stream)
       G16_HIP(hipEventCreate(&c.mev[i][0]));
       G16_HIP(hipEventCreate(&c.mev[i][1]));
-    }
-    if (serial) {
-      c.wst = c.wst2 = c.st;
-    } else {
-      // the G2 lane (B2) is the longest chain after the H chain: high priority as well
-      G16_HIP(hipStreamCreateWithPriority(&c.wst, hipStreamNonBlocking, prio_lo));
-      G16_HIP(hipStreamCreateWithPriority(&c.wst2, hipStreamNonBlocking, prio_hi));
     }
     const size_t vb = (size_t)P->N * sizeof(F29);
     G16_HIP(hipMalloc(&c.d_a, vb));
@@ -549,8 +567,9 @@ static void trace_host(const char* what, const std::chrono::steady_clock::time_p
 // Scheduling knobs (sweeps; the defaults are the measured optimum):
 //   G16_ACC_WAVES = "abc": wavefronts per SIMD of the persistent accumulate grids of the witness G1 lane, the
 //                   witness G2 lane and the H-MSM (0 = the kernel's full occupancy)
+//   G16_ACC_QUOTA = "abc": chunks of 64 tasks after which an accumulate wavefront retires (0 = persistent grid)
 //   G16_GATE      = "ab":  what the witness G1 / G2 accumulate kernels wait for: 0 nothing, 1 the NTT chain,
-//                   2 the H-MSM's sort, 3 the start of the H accumulate, 4 its end
+//                   2 the H-MSM's sort
 static uint32_t sched_digit(const char* name, int which, int len, uint32_t dflt) {
   const char* e = getenv(name);
   if (!e || (int)strlen(e) != len || e[which] < '0' || e[which] > '9') return dflt;
@@ -575,14 +594,15 @@ static int launch_witness_lanes(g16_prover* P, ProofCtx& c, bool h_launched) {
   int rc;
   hipEvent_t gates[2] = {nullptr, nullptr};
   for (int l = 0; l < 2; l++) {
-    // default (r02 sweeps, 40-proof medians): the G1 accumulate waits for the NTT chain -- its persistent grid
-    // would otherwise take the CUs from the transforms on the critical chain (8.66 -> 8.1 ms per proof)
-    const uint32_t gsel = sched_digit("G16_GATE", l, 2, l == 0 ? 1u : 0u);
+    // default: no gate.  (r02 sweeps, 40-proof medians, once every busy stream had its own hardware queue: real
+    // nzcp_live circuit 5.2 ms ungated against 6.1 with the G2 accumulate held back until the NTT chain is done and
+    // 6.3 with both; the 1.7 M synthetic circuit 8.1 ms either way -- holding work back only moves the collision.)
+    const uint32_t gsel = sched_digit("G16_GATE", l, 2, 0u);
     if (gsel == 1) gates[l] = c.ev[4];
-    else if (gsel >= 2 && gsel <= 4 && h_launched && P->grp[1].n) gates[l] = msm_event(c.ws[1], (int)gsel - 2);
+    else if (gsel == 2 && P->grp[1].n) gates[l] = msm_event(c.ws[1], 0);   // (recorded by the H front end, enqueued before)
   }
-  // ... and runs 3 of its 4 wavefronts per SIMD, which leaves room for the H-MSM's latency-bound front end
-  msm_set_waves(c.ws[0], sched_digit("G16_ACC_WAVES", 0, 3, 3), sched_digit("G16_ACC_WAVES", 1, 3, 0));
+  msm_set_waves(c.ws[0], sched_digit("G16_ACC_WAVES", 0, 3, 0), sched_digit("G16_ACC_WAVES", 1, 3, 0));
+  msm_set_quota(c.ws[0], sched_digit("G16_ACC_QUOTA", 0, 3, 0), sched_digit("G16_ACC_QUOTA", 1, 3, 0));
   if ((rc = msm_launch_lanes(P->grp[0], c.ws[0], c.wst, c.wst2, gates[0], gates[1]))) return rc;
   G16_HIP(hipEventRecord(c.mev[0][1], c.wst));
   if (P->b2_solo) {
@@ -614,14 +634,24 @@ static int launch_qap_ntt(g16_prover* P, ProofCtx& c, const Fr* d_w, uint32_t ma
   }
   return G16_OK;
 }
-// P = A'.B' - C' over [lo, hi) of the domain, then the H-MSM of this handle's point range
-static int launch_join_h(g16_prover* P, ProofCtx& c, uint32_t lo, uint32_t hi, bool joined = false) {
+// P = A'.B' - C' over [lo, hi) of the domain, then the front end (sort) of the H-MSM of this handle's point range
+static int launch_join_h_front(g16_prover* P, ProofCtx& c, uint32_t lo, uint32_t hi, bool joined = false) {
   int rc;
   if (!joined && hi > lo && (rc = ntt_join_abc(c.d_a + lo, c.d_b + lo, c.d_c + lo, c.d_p + lo, hi - lo, c.st))) return rc;
   G16_HIP(hipEventRecord(c.ev[4], c.st));
-  msm_set_waves(c.ws[1], sched_digit("G16_ACC_WAVES", 2, 3, 0), 0);
   G16_HIP(hipEventRecord(c.mev[1][0], c.st));
-  if ((rc = msm_launch(P->grp[1], c.ws[1], c.d_p, c.st, c.st))) return rc;
+  return msm_launch_front(P->grp[1], c.ws[1], c.d_p, c.st);
+}
+// ... and its accumulate / combine / reduce.  G16_HGATE (sweeps): what the H accumulate waits for: 0 nothing, 1 the
+// end of the witness G2 lane, 2 both witness lanes
+static int launch_h_lanes(g16_prover* P, ProofCtx& c, bool w_launched) {
+  int rc;
+  msm_set_waves(c.ws[1], sched_digit("G16_ACC_WAVES", 2, 3, 0), 0);
+  msm_set_quota(c.ws[1], sched_digit("G16_ACC_QUOTA", 2, 3, 0), 0);
+  const uint32_t hg = w_launched ? sched_digit("G16_HGATE", 0, 1, 0) : 0;
+  if (hg >= 2 && P->grp[0].n && msm_event(c.ws[0], 3)) G16_HIP(hipStreamWaitEvent(c.st, msm_event(c.ws[0], 3), 0));
+  hipEvent_t gate = (hg >= 1 && P->grp[0].n) ? msm_event(c.ws[0], 4) : nullptr;
+  if ((rc = msm_launch_lanes(P->grp[1], c.ws[1], c.st, c.st, gate, nullptr))) return rc;
   G16_HIP(hipEventRecord(c.mev[1][1], c.st));
   return G16_OK;
 }
@@ -639,10 +669,12 @@ static int launch_ctx(g16_prover* P, ProofCtx& c, const Fr* d_w) {
   // a sharded handle joins only the slice of the domain its H bases cover
   uint32_t lo, hi;
   shard_range(P->N, P->shard_rank, P->shard_count, lo, hi);
-  if ((rc = launch_join_h(P, c, lo, hi, fuse))) return rc;
-  trace_host("h msm", th0);
-  if ((rc = launch_witness_lanes(P, c, true))) return rc;
+  if ((rc = launch_join_h_front(P, c, lo, hi, fuse))) return rc;
+  trace_host("h front end", th0);
+  if ((rc = launch_witness_lanes(P, c, false))) return rc;
   trace_host("witness lanes", th0);
+  if ((rc = launch_h_lanes(P, c, true))) return rc;
+  trace_host("h lanes", th0);
   return G16_OK;
 }
 
@@ -815,7 +847,8 @@ int g16_shard_end(g16_prover* p, uint32_t slot, const void* const slices[3], uin
       rc = G16_E_HIP;
     }
   }
-  if (!rc) rc = launch_join_h(p, c, lo, hi);
+  if (!rc) rc = launch_join_h_front(p, c, lo, hi);
+  if (!rc) rc = launch_h_lanes(p, c, false);
   Partial part;
   if (rc) {   // drain the witness group that g16_shard_begin started, then report
     (void)collect_witness_msms(p, c, part);

@@ -17,11 +17,15 @@ def main():
     with open(os.path.join(ROOT, "gpurun_out", "sweep.txt"), "a") as log:
         for st in settings:
             env = dict(os.environ)
+            more = []
             for kv in st.split():
+                if kv.startswith("--"):       # a bench.py argument, e.g. --circuit=synthetic
+                    more.append(kv)
+                    continue
                 k, v = kv.split("=", 1)
                 env[k] = v
             try:
-                out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + extra, env=env,
+                out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + extra + more, env=env,
                                      capture_output=True, text=True, timeout=280)
                 line = out.stdout.strip().splitlines()[-1]
                 d = json.loads(line)
