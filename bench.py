@@ -262,6 +262,8 @@ def main():
             names = [("Jack", "Sparrow", "1960-04-16"), ("Anne-Marie", "Te Whare", "1987-11-30"), ("Li", "Wei", "2001-02-03"),
                      ("Aroha", "Ngata", "1975-07-21"), ("Sione", "Tuilagi", "1990-12-01"), ("Mere", "Hohepa", "1968-03-15"),
                      ("Tama", "Parata", "1983-09-09"), ("Olivia", "Smith", "1999-05-27")]
+            if not live:   # nzcp_exampleTest's MaxToBeSignedBytes = 314 is the example pass's own length: no longer names
+                names = [n for n in names if len(n[0]) + len(n[1]) <= 11]
             g_, f_, d_ = names[i % len(names)]
             return nzcp_pass.to_be_signed(g_, f_, d_, live=live, exp=1951416330 - i)
         out = amd.nzcp_circuit_setup(nz_params, nz_pass(0), SEED, threads)
@@ -389,6 +391,19 @@ def main():
                     "mode": f"{world} independent unsharded provers, one per GPU, no collective",
                     "sharded_proof_equals_unsharded": True}
         rp.close()
+    # the ABI entry a snarkjs user hits: g16_prove = witness upload over PCIe + the same pipeline
+    incl_upload = None
+    if world == 1:
+        for _ in range(2):
+            assert lib.g16_prove(prover._h, wtns, len(wtns), r, s, ctypes.byref(pr), pub) == 0, lib.g16_last_error()
+        t_u = []
+        for _ in range(min(K, 10)):
+            ts = time.perf_counter()
+            assert lib.g16_prove(prover._h, wtns, len(wtns), r, s, ctypes.byref(pr), pub) == 0, lib.g16_last_error()
+            t_u.append(1e3 * (time.perf_counter() - ts))
+        t_u.sort()
+        incl_upload = {"ms_per_proof_p50": round(t_u[len(t_u) // 2], 3), "proofs_per_sec": round(1e3 / t_u[len(t_u) // 2], 3),
+                       "entry": "g16_prove(wtns in pageable host memory): upload + canonicity check + proof, no staging"}
     batch = None
     if world == 1 and args.batch_streams > 0:
         batch = batch_leg(amd, args, None, wtns, prover, r, s, log)
@@ -487,6 +502,8 @@ def main():
                                           if costs else {"note": "lib/kernel_costs.json missing or generated from other sources: run make"}),
                          "note": "integer-VALU bound: ~2.2k VALU instructions (1.47k v_mad_u64_u32) per mixed addition at ~5 cycles each, 13 (H, c = 20, precomputed windows) to 20 (witness, c = 13) additions per 96-byte point; see DESIGN.md 3.3"},
         }
+        if incl_upload is not None:
+            out["value_incl_upload"] = incl_upload
         if batch is not None:
             out["batch_throughput"] = batch
         if replicas is not None:

@@ -73,6 +73,9 @@ struct QapCsr {
 static constexpr uint32_t kQapLongRow = 16;
 // a[c] = sum val*w[col] (lazy Montgomery), b likewise, cc = a*b; w is the standard-form witness
 int qap_eval(const QapCsr& q, const Fr* w_std, F29* a, F29* b, F29* cc, hipStream_t st);
+// canonicity of the staged witness words: *h_flag (pinned) <- lowest index of a word >= r, or 0xffffffff, once `st`
+// has passed this point
+int qap_check_witness(const Fr* w_std, uint32_t n, uint32_t* d_flag, uint32_t* h_flag, hipStream_t st);
 // zkey section-4 words (device, canonical) -> the lazy coefficient format, once at create
 int qap_convert_coefs(const Fr* in, F29* out, size_t n, hipStream_t st);
 

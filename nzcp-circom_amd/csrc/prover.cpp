@@ -138,6 +138,8 @@ struct g16_prover {
     F29 *d_a = nullptr, *d_b = nullptr, *d_c = nullptr;   // QAP/NTT vectors, lazy 9x29 format
     Fr* d_p = nullptr;                                    // H-MSM scalars, standard form
     Fr* d_w = nullptr;                                    // batch mode: this context's witness copy
+    uint32_t* d_flag = nullptr;                           // canonicity check of the witness this context proves
+    uint32_t* h_flag = nullptr;                           // ... its pinned host copy
     g16_timings tm{};
   };
   static constexpr int kCtx = 2;
@@ -151,8 +153,9 @@ struct g16_prover {
     (void)hipSetDevice(device);
     for (Fr* p : slot_dev) if (p) (void)hipFree(p);
     for (auto& c : ctx) {
-      void* vs[] = {c.d_a, c.d_b, c.d_c, c.d_p, c.d_w};
+      void* vs[] = {c.d_a, c.d_b, c.d_c, c.d_p, c.d_w, c.d_flag};
       for (void* p : vs) if (p) (void)hipFree(p);
+      if (c.h_flag) (void)hipHostFree(c.h_flag);
       for (auto& w : c.ws) msm_workspace_destroy(w);
       if (c.wst && c.wst != c.st) (void)hipStreamDestroy(c.wst);
       if (c.wst2 && c.wst2 != c.st) (void)hipStreamDestroy(c.wst2);
@@ -398,6 +401,9 @@ static int create_impl(const uint8_t* zkey, size_t len, const g16_opts* opts, g1
     G16_HIP(hipMalloc(&c.d_b, vb));
     G16_HIP(hipMalloc(&c.d_c, vb));
     G16_HIP(hipMalloc(&c.d_p, (size_t)P->N * sizeof(Fr)));
+    G16_HIP(hipMalloc(&c.d_flag, 64));
+    G16_HIP(hipHostMalloc((void**)&c.h_flag, 64));
+    *c.h_flag = 0xffffffffu;
   }
   G16_HIP(hipStreamSynchronize(P->st));
   return G16_OK;
@@ -424,25 +430,19 @@ static int parse_wtns(const g16_prover* P, const uint8_t* wtns, size_t len, cons
   }
   if ((rc = need_section(f, 2, "wtns", s2))) return rc;
   if (s2.size != (uint64_t)nw * 32) { set_error("wtns: Invalid File format"); return G16_E_FORMAT; }
-  // Witness words must be canonical residues (what every circom witness calculator writes).  The
-  // signed-digit recoding of the MSM assumes scalars below r; reject anything else loudly instead of
-  // producing a wrong proof.  One pass over the top limbs (~1 ms at 1.7 M signals).
-  for (uint32_t i = 0; i < nw; i++) {
-    const uint8_t* w = s2.p + (size_t)i * 32;
-    const uint32_t top = rd32(w + 28);
-    if (top < kR[7]) continue;
-    uint32_t v[8];
-    memcpy(v, w, 32);
-    if (!scalar_lt_r(v)) {
-      set_error("wtns: signal " + std::to_string(i) + " is not reduced modulo the scalar field");
-      return G16_E_FORMAT;
-    }
-  }
+  // (canonicity of the words -- every one below r -- is checked on the device after the upload: qap_check_witness)
   *body = s2.p;
   return G16_OK;
 }
 
-static int stage_impl(g16_prover* P, uint32_t slot, const uint8_t* wtns, size_t len) {
+// the device-side canonicity verdict of the witness context `c` last checked (valid once its stream has drained)
+static int witness_ok(const g16_prover::ProofCtx& c) {
+  if (*c.h_flag == 0xffffffffu) return G16_OK;
+  set_error("wtns: signal " + std::to_string(*c.h_flag) + " is not reduced modulo the scalar field");
+  return G16_E_FORMAT;
+}
+
+static int stage_impl(g16_prover* P, uint32_t slot, const uint8_t* wtns, size_t len, bool sync = true) {
   const uint8_t* body = nullptr;
   int rc = parse_wtns(P, wtns, len, &body);
   if (rc) return rc;
@@ -454,11 +454,13 @@ static int stage_impl(g16_prover* P, uint32_t slot, const uint8_t* wtns, size_t 
   G16_HIP(hipEventRecord(c0.ev[0], P->st));
   G16_HIP(hipMemcpyAsync(P->slot_dev[slot], body, (size_t)P->nVars * 32, hipMemcpyHostToDevice, P->st));
   G16_HIP(hipEventRecord(c0.ev[1], P->st));
+  if ((rc = qap_check_witness(P->slot_dev[slot], P->nVars, c0.d_flag, c0.h_flag, P->st))) return rc;
+  P->slot_pub[slot].assign(body + 32, body + 32 + (size_t)P->nPublic * 32);
+  if (!sync) return G16_OK;   // g16_prove: the proof pipeline follows on the same stream; witness_ok() after it
   G16_HIP(hipStreamSynchronize(P->st));
   (void)hipEventElapsedTime(&c0.tm.upload_ms, c0.ev[0], c0.ev[1]);
   P->tm.upload_ms = c0.tm.upload_ms;
-  P->slot_pub[slot].assign(body + 32, body + 32 + (size_t)P->nPublic * 32);
-  return G16_OK;
+  return witness_ok(c0);
 }
 
 // Proof assembly on the host: O(1) work, in two halves.  The blinding terms that
@@ -875,10 +877,8 @@ int g16_prove_finish(g16_prover* p, uint32_t slot, const uint8_t* partials, uint
   return rc;
 }
 
-int g16_prove_staged(g16_prover* p, uint32_t slot, const uint8_t r[32], const uint8_t s[32], g16_proof* out,
-                     uint8_t* pub) {
-  if (!p || !out) { set_error("NULL argument"); return G16_E_ARG; }
-  std::lock_guard<std::mutex> lk(p->mu);
+static int prove_staged_locked(g16_prover* p, uint32_t slot, const uint8_t r[32], const uint8_t s[32], g16_proof* out,
+                               uint8_t* pub) {
   if (p->shard_count != 1) { set_error("sharded handle: use g16_prove_partial/g16_prove_finish"); return G16_E_STATE; }
   if (slot >= p->slot_dev.size() || !p->slot_dev[slot]) { set_error("witness slot not staged"); return G16_E_STATE; }
   Blinding bl;
@@ -894,11 +894,27 @@ int g16_prove_staged(g16_prover* p, uint32_t slot, const uint8_t r[32], const ui
   return rc;
 }
 
+int g16_prove_staged(g16_prover* p, uint32_t slot, const uint8_t r[32], const uint8_t s[32], g16_proof* out,
+                     uint8_t* pub) {
+  if (!p || !out) { set_error("NULL argument"); return G16_E_ARG; }
+  std::lock_guard<std::mutex> lk(p->mu);
+  return prove_staged_locked(p, slot, r, s, out, pub);
+}
+
 int g16_prove(g16_prover* p, const uint8_t* wtns, size_t wtns_len, const uint8_t r[32], const uint8_t s[32],
               g16_proof* out, uint8_t* pub) {
-  int rc = g16_stage_witness(p, 0, wtns, wtns_len);
+  if (!p || !out) { set_error("NULL argument"); return G16_E_ARG; }
+  if (p->shard_count != 1) { set_error("sharded handle: use g16_prove_partial/g16_prove_finish"); return G16_E_STATE; }
+  std::lock_guard<std::mutex> lk(p->mu);
+  // upload and proof pipeline back to back on the main stream: no host synchronisation in between (the caller's
+  // buffer stays valid until this call returns), the canonicity verdict of the words is read after the proof
+  int rc = stage_impl(p, 0, wtns, wtns_len, /*sync=*/false);
   if (rc) return rc;
-  return g16_prove_staged(p, 0, r, s, out, pub);
+  rc = prove_staged_locked(p, 0, r, s, out, pub);
+  (void)hipEventElapsedTime(&p->ctx[0].tm.upload_ms, p->ctx[0].ev[0], p->ctx[0].ev[1]);
+  p->tm.upload_ms = p->ctx[0].tm.upload_ms;
+  const int wrc = witness_ok(p->ctx[0]);
+  return wrc ? wrc : rc;
 }
 
 int g16_prove_batch(g16_prover* p, const uint8_t* const* wtns, const size_t* wtns_lens, size_t count,
@@ -918,7 +934,9 @@ int g16_prove_batch(g16_prover* p, const uint8_t* const* wtns, const size_t* wtn
       (void)collect_ctx(p, c, part);
       return bl_rc[i % g16_prover::kCtx];
     }
-    return collect_and_assemble(p, c, bl[i % g16_prover::kCtx], &out[i]);
+    const int frc = collect_and_assemble(p, c, bl[i % g16_prover::kCtx], &out[i]);
+    const int wrc = witness_ok(c);
+    return wrc ? wrc : frc;
   };
   for (size_t i = 0; i < count; i++) {
     ProofCtx& c = p->ctx[i % g16_prover::kCtx];
@@ -932,6 +950,7 @@ int g16_prove_batch(g16_prover* p, const uint8_t* const* wtns, const size_t* wtn
     G16_HIP(hipSetDevice(p->device));
     if (!c.d_w) G16_HIP(hipMalloc(&c.d_w, wbytes));
     G16_HIP(hipMemcpyAsync(c.d_w, body, wbytes, hipMemcpyHostToDevice, c.st));
+    if ((rc = qap_check_witness(c.d_w, p->nVars, c.d_flag, c.h_flag, c.st))) return rc;
     if (pub && p->nPublic) memcpy(pub + i * (size_t)p->nPublic * 32, body + 32, (size_t)p->nPublic * 32);
     if ((rc = launch_ctx(p, c, c.d_w))) return rc;
     bl_rc[i % g16_prover::kCtx] = prepare_blinding(&p->kp, rs ? rs + i * 64 : nullptr, rs ? rs + i * 64 + 32 : nullptr,

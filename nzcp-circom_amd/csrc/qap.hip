@@ -93,6 +93,29 @@ int qap_eval(const QapCsr& q, const Fr* w_std, F29* a, F29* b, F29* cc, hipStrea
   return G16_OK;
 }
 
+// Witness words must be canonical residues (what every circom witness calculator writes): the signed-digit
+// recoding of the MSM assumes scalars below r.  flag[0] <- the lowest index of a word >= r (0xffffffff: none).
+// On the device: the words are in HBM anyway, and the host-side scan cost ~1 ms of every g16_prove (r01).
+__global__ __launch_bounds__(256) void qap_check_witness_kernel(const Fr* __restrict__ w, uint32_t n, uint32_t* __restrict__ flag) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  static const uint32_t kR[8] = G16_FR_P;
+  const Fr x = w[i];
+  bool lt = false, decided = false;
+#pragma unroll
+  for (int k = 7; k >= 0; k--) {
+    if (!decided && x.v[k] != kR[k]) { lt = x.v[k] < kR[k]; decided = true; }
+  }
+  if (!lt) atomicMin(flag, i);
+}
+int qap_check_witness(const Fr* w_std, uint32_t n, uint32_t* d_flag, uint32_t* h_flag, hipStream_t st) {
+  G16_HIP(hipMemsetAsync(d_flag, 0xff, 4, st));
+  if (n) qap_check_witness_kernel<<<(n + 255) / 256, 256, 0, st>>>(w_std, n, d_flag);
+  G16_HIP(hipGetLastError());
+  G16_HIP(hipMemcpyAsync(h_flag, d_flag, 4, hipMemcpyDeviceToHost, st));
+  return G16_OK;
+}
+
 int qap_convert_coefs(const Fr* in, F29* out, size_t n, hipStream_t st) {
   if (n == 0) return G16_OK;
   qap_convert_kernel<<<(unsigned)((n + 255) / 256), 256, 0, st>>>(in, out, n);

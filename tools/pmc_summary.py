@@ -11,7 +11,7 @@ import shutil
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
 src = sys.argv[2] if len(sys.argv) > 2 else os.path.join(ROOT, "gpurun_out", "final")
 prof = os.path.join(ROOT, "profiles")
 
@@ -49,9 +49,17 @@ acc2 = [r for r in p2 if "msm_accumulate_kernel<g16::Fq29Ops>" in r["name"]]
 fetch = [int(r["FETCH_SIZE"] * 1024) for r in acc1]
 write = [int(r["WRITE_SIZE"] * 1024) for r in acc2]
 miss = [int(r["TCC_MISS_sum"] * 64) for r in acc2]
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+import kernel_costs  # noqa: E402
+bench = json.load(open(os.path.join(src, "bench.json")))
+cfgw = bench["config"]["workload"]
+m = re.search(r"nVars=(\d+), nConstraints=(-?\d+)", cfgw)
+circuit = "nzcp_live" if cfgw.startswith("nzcp_live") else "nzcp_example" if cfgw.startswith("nzcp_example") else "synthetic"
 traffic = {
     "kernel": "msm_accumulate_kernel<Fq29Ops>",
-    "launches": "the four G1 launches (C, A, B1, H in launch order) of one proof, serial-MSM mode "
+    "kernel_src_sha256": kernel_costs.kernel_source_hash(),
+    "workload_id": f"{circuit}:{m.group(1)}:{m.group(2)}",
+    "launches": "the two G1 launches of one proof in launch order (fused witness group A+B1+C, then H), serial-MSM mode "
                 "(G16_SERIAL_MSM=1), default bench workload",
     "fetch_bytes_per_launch": fetch, "write_bytes_per_launch": write, "tcc_miss_x64B_per_launch": miss,
     "avg_traffic_bytes_per_launch": int(sum(f + w for f, w in zip(fetch, write)) / max(1, len(fetch))),
@@ -80,7 +88,7 @@ with open(os.path.join(prof, f"{tag}_pmc_accumulate.txt"), "w") as o:
                 f"active/wave_cyc={r.get('SQ_ACTIVE_INST_ANY', 0) / wc:.2f}\n")
     o.write("# pass 1: FETCH_SIZE (KiB, raw)   pass 2: WRITE_SIZE (KiB), TCC_HIT_sum, TCC_MISS_sum\n")
     for a, b in zip(p1, p2):
-        if "accumulate" in a["name"] or "ntt_pass" in a["name"] or "sort_kernel" in a["name"]:
+        if any(k in a["name"] for k in ("accumulate", "ntt_pass", "ntt_last", "bin_pass", "bin_sort", "qap_eval")):
             o.write(f"{short(a['name']):44s} grid={a['grid']:8d} dur_ms={a['dur_ms']:.3f} FETCH_SIZE={a.get('FETCH_SIZE', 0):.4g} "
                     f"WRITE_SIZE={b.get('WRITE_SIZE', 0):.4g} TCC_HIT={b.get('TCC_HIT_sum', 0):.4g} TCC_MISS={b.get('TCC_MISS_sum', 0):.4g}\n")
 print(json.dumps(traffic, indent=1))
