@@ -240,6 +240,9 @@ def main():
     amd.load()
     ncpu = os.cpu_count() or 1
     threads = max(1, ncpu // world)
+    # the trapdoor setup's fixed-base multiplications run on this rank's GPU (csrc/setup_gpu.hip; same key bytes as the
+    # host-thread path, tests/test_gpu_setup.py) -- untimed preparation either way
+    amd.setup_device(dev)
     t0 = time.time()
     if args.sha256_blocks > 0:
         import hashlib

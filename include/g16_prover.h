@@ -203,6 +203,12 @@ int g16_synth_witness(uint32_t n_vars, uint32_t n_public, uint32_t n_constraints
  * real nzcp_live R1CS and benchmark its true shape; NOT a ceremony -- the trapdoor is known. */
 int g16_r1cs_setup(const uint8_t* r1cs, size_t r1cs_len, uint64_t seed, int threads, uint8_t** zkey,
                    size_t* zkey_len, uint8_t** vkey, size_t* vkey_len);
+/* Where the fixed-base multiplications of every *_setup entry point run ("trapdoor setup at scale on
+ * GPU (fixed-base MSM kernel)"; stands in for `snarkjs groth16 setup`, /root/reference/Makefile:30-31 records the PLONK
+ * twin): device >= 0 = that HIP device (csrc/setup_gpu.hip: one lane per scalar over a small L2-resident window table,
+ * batched conversion to affine), -1 = host threads (the default).  Process-wide; the zkey bytes are the same either way.
+ * A setup with the device path selected and no GPU present returns G16_E_NOGPU. */
+int g16_setup_device(int device);
 
 /* Test-only: a REAL constraint system for BASELINE config 5 -- `blocks` chained SHA-256 compressions
  * d_{i+1} = SHA-256(d_i) over a 32-byte private message, bit-level R1CS in the style of the circomlib sha256

@@ -58,7 +58,7 @@ EXPORTS = ["g16_create", "g16_prove", "g16_prove_batch", "g16_stage_witness", "g
            "g16_sha256_chain_setup", "g16_sha256_message_setup", "g16_nzcp_fixed_layout_setup",
            "g16_f29_op", "g16_x29_op", "g16_qap_eval", "g16_shard_begin", "g16_shard_end",
            "g16_multi_create", "g16_multi_prove", "g16_multi_get_info", "g16_multi_destroy",
-           "g16_nzcp_gadget", "g16_nzcp_circuit_setup"]
+           "g16_nzcp_gadget", "g16_nzcp_circuit_setup", "g16_setup_device"]
 
 
 def load():
@@ -110,6 +110,7 @@ def load():
                                     C.POINTER(vp), C.POINTER(sz)]
     lib.g16_synth_witness.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint64, C.c_uint64,
                                       C.POINTER(vp), C.POINTER(sz)]
+    lib.g16_setup_device.argtypes = [C.c_int]
     lib.g16_r1cs_setup.argtypes = [C.c_char_p, sz, C.c_uint64, C.c_int, C.POINTER(vp), C.POINTER(sz), C.POINTER(vp), C.POINTER(sz)]
     lib.g16_sha256_chain_setup.argtypes = [C.c_uint32, C.c_char_p, C.c_uint64, C.c_int] + [C.c_void_p] * 8
     lib.g16_sha256_message_setup.argtypes = [C.c_char_p, C.c_uint32, C.c_uint64, C.c_int] + [C.c_void_p] * 8
@@ -460,6 +461,11 @@ def nzcp_circuit_setup(params, tbs, seed, threads=0, want_zkey=True, want_r1cs=F
 
 def sha256_message_setup(msg, seed, threads=0, want_zkey=True, want_r1cs=False):
     return sha256_chain_setup(0, msg, seed, threads, want_zkey, want_r1cs, chain=False)
+
+
+def setup_device(device):
+    """Where the fixed-base multiplications of the *_setup builders run: a HIP device ordinal, or -1 = host threads."""
+    _check(load().g16_setup_device(int(device)))
 
 
 def r1cs_setup(r1cs, seed, threads=0):

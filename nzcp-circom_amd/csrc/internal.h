@@ -27,6 +27,11 @@ const char* get_error();
   } while (0)
 
 
+// ---------------------------------------------------------------- trapdoor setup on the device (setup_gpu.hip)
+// out[i] = [k_i] G as affine Montgomery bytes; tbl = host table [nwin][2^wb - 1] of d * 2^(wb j) * G, k in Montgomery form
+int setup_fixed_mul_g1(int device, const G1Affine* tbl, int wb, int nwin, const Fr* ks_mont, size_t n, uint8_t* out);
+int setup_fixed_mul_g2(int device, const G2Affine* tbl, int wb, int nwin, const Fr* ks_mont, size_t n, uint8_t* out);
+
 // ---------------------------------------------------------------- NTT (ntt.hip)
 struct NttPass { int lo_bits, S, tb; };
 struct NttTables {

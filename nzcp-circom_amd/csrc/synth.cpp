@@ -14,6 +14,7 @@
 #include <array>
 #include <string.h>
 
+#include <atomic>
 #include <thread>
 
 #include "internal.h"
@@ -71,6 +72,9 @@ struct Xo {
 };
 
 using FrM = Fr;  // Montgomery-form Fr throughout this file
+
+// where the fixed-base multiplications of the *_setup entry points run: -1 = host threads, >= 0 = that HIP device
+static std::atomic<int> g_setup_device{-1};
 
 FrM fr_u64(uint64_t v) {
   Fr a = fp_zero<FrParams>();
@@ -430,7 +434,10 @@ static int setup_core(const Circuit& c, uint64_t seed, int threads, uint8_t** zk
   lagrange_at(L + 1, tau, 1, 2, N, hs);  // L^(2N)_{2i+1}(tau)
   for (auto& x : hs) x = fp_mul(x, dinv);
 
-  const int wb = n >= 20000 ? 16 : 8;
+  // fixed-base multiplications: host threads, or the device selected by g16_setup_device (setup_gpu.hip; a
+  // small-window table then -- the device has the lanes, the table should stay in its L2)
+  const int dev = g_setup_device.load();
+  const int wb = dev >= 0 ? 8 : (n >= 20000 ? 16 : 8);
   FixedBase<FqOps> fb1;
   FixedBase<Fq2Ops> fb2;
   G1Affine g1;
@@ -440,6 +447,17 @@ static int setup_core(const Circuit& c, uint64_t seed, int threads, uint8_t** zk
   g2.x.a = Fq{G16_G2X0}; g2.x.b = Fq{G16_G2X1}; g2.y.a = Fq{G16_G2Y0}; g2.y.b = Fq{G16_G2Y1};
   build_table(fb1, g1, wb, threads);
   build_table(fb2, g2, wb, threads);
+  int mul_rc = G16_OK;
+  auto mul1 = [&](const FrM* ks, size_t cnt, uint8_t* out) {
+    if (dev < 0 || cnt < 64) { fixed_mul_many(fb1, ks, cnt, out, threads); return; }
+    const int r = setup_fixed_mul_g1(dev, fb1.tbl.data(), fb1.wb, fb1.nwin, ks, cnt, out);
+    if (r && !mul_rc) mul_rc = r;
+  };
+  auto mul2 = [&](const FrM* ks, size_t cnt, uint8_t* out) {
+    if (dev < 0 || cnt < 64) { fixed_mul_many(fb2, ks, cnt, out, threads); return; }
+    const int r = setup_fixed_mul_g2(dev, fb2.tbl.data(), fb2.wb, fb2.nwin, ks, cnt, out);
+    if (r && !mul_rc) mul_rc = r;
+  };
 
   const size_t nC = (size_t)n - p - 1;
   const size_t hdr2 = 4 + 32 + 4 + 32 + 12 + 64 + 64 + 128 + 128 + 64 + 128;
@@ -475,21 +493,22 @@ static int setup_core(const Circuit& c, uint64_t seed, int threads, uint8_t** zk
     memcpy(q, g2pts + 256, 128);              // delta2
   }
   uint8_t* p3 = sec(3);
-  fixed_mul_many(fb1, kic.data(), kic.size(), p3, threads);
+  mul1(kic.data(), kic.size(), p3);
   uint8_t* p4 = sec(4);
   memcpy(p4, s4.data(), s4.size());
   uint8_t* p5 = sec(5);
-  fixed_mul_many(fb1, u.data(), n, p5, threads);
+  mul1(u.data(), n, p5);
   uint8_t* p6 = sec(6);
-  fixed_mul_many(fb1, v.data(), n, p6, threads);
+  mul1(v.data(), n, p6);
   uint8_t* p7 = sec(7);
-  fixed_mul_many(fb2, v.data(), n, p7, threads);
+  mul2(v.data(), n, p7);
   uint8_t* p8 = sec(8);
-  fixed_mul_many(fb1, kc.data(), kc.size(), p8, threads);
+  mul1(kc.data(), kc.size(), p8);
   uint8_t* p9 = sec(9);
-  fixed_mul_many(fb1, hs.data(), hs.size(), p9, threads);
+  mul1(hs.data(), hs.size(), p9);
   uint8_t* p10 = sec(10);
   memset(p10, 0, sizes[10]);
+  if (mul_rc) { free(z.p); return mul_rc; }
   *zkey = z.p;
   *zkey_len = z.len;
   if (vkey && vkey_len) {
@@ -1134,4 +1153,10 @@ extern "C" int g16_r1cs_setup(const uint8_t* r1cs, size_t r1cs_len, uint64_t see
   uint64_t need = (uint64_t)c.m + c.p + 1;
   if (need > ((uint64_t)1 << 27)) { set_error("r1cs: circuit too large"); return G16_E_ARG; }
   return setup_core(c, seed, threads, zkey, zkey_len, vkey, vkey_len);
+}
+
+extern "C" int g16_setup_device(int device) {
+  if (device < -1) { set_error("setup: bad device ordinal"); return G16_E_ARG; }
+  g_setup_device.store(device);
+  return G16_OK;
 }

@@ -101,6 +101,15 @@ def test_no_cpu_fallback(amd):
     with pytest.raises(amd.G16Error) as e:
         amd.multiexp(1, bytes(64), bytes(32))
     assert e.value.code == -4
+    # the device path of the trapdoor setup, once selected, does not drop back to the host threads either
+    amd.setup_device(0)
+    try:
+        with pytest.raises(amd.G16Error) as e:
+            amd.synth_setup(150, 6, 120, 2, 2)
+        assert e.value.code == -4
+    finally:
+        amd.setup_device(-1)
+    assert len(amd.synth_setup(150, 6, 120, 2, 2)[0]) > 0
 
 
 @pytest.mark.parametrize("n,p,m,seed", [(24, 2, 12, 1), (200, 7, 160, 13)])
