@@ -257,6 +257,33 @@ int g16_nzcp_circuit_setup(const uint32_t params[7], const uint8_t* tbs, uint32_
                            size_t* vkey_len, uint8_t** r1cs, size_t* r1cs_len, uint32_t* n_constraints);
 void g16_free(void* p);
 
+/* ---------------------------------------------------------------------------------------------------------------
+ * Groth16 batch verifier on the device (the acceptance check of SURVEY 3.4).
+ * [EXT] snarkjs groth16_verify.js `groth16.verify(vk, publicSignals, proof)`: cpub = IC[0] + sum pub_i IC[i+1], then
+ * curve.pairingEq(-pi_a, pi_b, cpub, vk_gamma_2, pi_c, vk_delta_2, vk_alpha_1, vk_beta_2)  (pins
+ * /root/reference/yarn.lock:987-1001; verification_key.json layout SURVEY App. A.5).  One handle = one verification
+ * key resident on one GPU; a batch call returns one verdict per proof (the verdicts of one-at-a-time verification).
+ *
+ * vkey: alpha1 (64 B) | beta2 (128) | gamma2 (128) | delta2 (128) | IC[0..n_public] (64 each), affine little-endian,
+ *       G2 as x.c0 | x.c1 | y.c0 | y.c1; montgomery = 1: Montgomery residues (what the *_setup entry points return),
+ *       0: standard integers (what verification_key.json holds).  Rejected with G16_E_FORMAT: wrong length, a
+ *       coordinate >= q, a point off its curve.
+ * proofs: g16_proof as g16_prove writes them (standard form).  pubs: count * n_public * 32 bytes, standard LE
+ *       (any 256-bit value: snarkjs reduces modulo r, so does the scalar multiplication here).
+ * ok[i] = 1 accepted, 0 rejected (pairing product != 1, or a proof coordinate >= q, or a proof point off its curve).
+ * No CPU path: G16_E_NOGPU without a HIP device. */
+typedef struct g16_verifier g16_verifier;
+int g16_verifier_create(const uint8_t* vkey, size_t vkey_len, uint32_t n_public, int montgomery, int device,
+                        g16_verifier** out);
+int g16_verify_batch(g16_verifier* v, const g16_proof* proofs, const uint8_t* pubs, size_t count, uint8_t* ok);
+/* device time of the last batch, ms: [0] vk_x (public-signal MSMs), [1] Miller loops, [2] final exponentiations */
+int g16_verifier_timings(const g16_verifier* v, float ms[3]);
+void g16_verifier_destroy(g16_verifier* v);
+/* Layer-test operator: `count` pairs (P in G1, Q in G2; six standard-form 32-byte words each: px py qx.c0 qx.c1 qy.c0
+ * qy.c1, both on their curves, neither infinity) -> twelve standard-form words per pair: the pairing value the verifier
+ * kernels compute, as the coefficients (c0, c1) of W^0..W^5 in the tower Fq12 = Fq2[W]/(W^6 - (9+u)). */
+int g16_pairing_op(int device, const uint8_t* in, uint32_t count, uint8_t* out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -58,7 +58,8 @@ EXPORTS = ["g16_create", "g16_prove", "g16_prove_batch", "g16_stage_witness", "g
            "g16_sha256_chain_setup", "g16_sha256_message_setup", "g16_nzcp_fixed_layout_setup",
            "g16_f29_op", "g16_x29_op", "g16_qap_eval", "g16_shard_begin", "g16_shard_end",
            "g16_multi_create", "g16_multi_prove", "g16_multi_get_info", "g16_multi_destroy",
-           "g16_nzcp_gadget", "g16_nzcp_circuit_setup", "g16_setup_device"]
+           "g16_nzcp_gadget", "g16_nzcp_circuit_setup", "g16_setup_device",
+           "g16_verifier_create", "g16_verify_batch", "g16_verifier_timings", "g16_verifier_destroy", "g16_pairing_op"]
 
 
 def load():
@@ -111,6 +112,12 @@ def load():
     lib.g16_synth_witness.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint64, C.c_uint64,
                                       C.POINTER(vp), C.POINTER(sz)]
     lib.g16_setup_device.argtypes = [C.c_int]
+    lib.g16_verifier_create.argtypes = [C.c_char_p, sz, C.c_uint32, C.c_int, C.c_int, C.POINTER(vp)]
+    lib.g16_verify_batch.argtypes = [vp, C.c_char_p, C.c_char_p, sz, C.c_char_p]
+    lib.g16_verifier_timings.argtypes = [vp, C.POINTER(C.c_float)]
+    lib.g16_verifier_destroy.argtypes = [vp]
+    lib.g16_verifier_destroy.restype = None
+    lib.g16_pairing_op.argtypes = [C.c_int, C.c_char_p, C.c_uint32, C.c_char_p]
     lib.g16_r1cs_setup.argtypes = [C.c_char_p, sz, C.c_uint64, C.c_int, C.POINTER(vp), C.POINTER(sz), C.POINTER(vp), C.POINTER(sz)]
     lib.g16_sha256_chain_setup.argtypes = [C.c_uint32, C.c_char_p, C.c_uint64, C.c_int] + [C.c_void_p] * 8
     lib.g16_sha256_message_setup.argtypes = [C.c_char_p, C.c_uint32, C.c_uint64, C.c_int] + [C.c_void_p] * 8
@@ -499,6 +506,90 @@ def vkey_json(vkey, n_public):
             "vk_alpha_1": g1(vkey[0:64]), "vk_beta_2": g2(vkey[64:192]), "vk_gamma_2": g2(vkey[192:320]),
             "vk_delta_2": g2(vkey[320:448]),
             "IC": [g1(vkey[448 + 64 * i:512 + 64 * i]) for i in range(n_public + 1)]}
+
+
+# ------------------------------------------------------------------ verifier (snarkjs groth16.verify, batched)
+def _le32(x):
+    return (int(x) % (1 << 256)).to_bytes(32, "little")
+
+
+def proof_from_obj(obj):
+    """proof.json object (decimal strings) -> g16_proof bytes (affine standard LE; infinity = zeros)."""
+    def g1(t):
+        return bytes(64) if str(t[2]) == "0" else _le32(t[0]) + _le32(t[1])
+    b = obj["pi_b"]
+    pb = bytes(128) if (str(b[2][0]), str(b[2][1])) == ("0", "0") else _le32(b[0][0]) + _le32(b[0][1]) + _le32(b[1][0]) + _le32(b[1][1])
+    return g1(obj["pi_a"]) + pb + g1(obj["pi_c"])
+
+
+def vkey_from_json(vk):
+    """verification_key.json object -> (point bytes in STANDARD form, nPublic) for Verifier(..., montgomery=False)."""
+    def g1(t):
+        return bytes(64) if str(t[2]) == "0" else _le32(t[0]) + _le32(t[1])
+
+    def g2(t):
+        if (str(t[2][0]), str(t[2][1])) == ("0", "0"):
+            return bytes(128)
+        return _le32(t[0][0]) + _le32(t[0][1]) + _le32(t[1][0]) + _le32(t[1][1])
+    n_public = int(vk["nPublic"])
+    if len(vk["IC"]) != n_public + 1:
+        raise G16Error(-2, "verification key: IC length does not match nPublic")
+    return (g1(vk["vk_alpha_1"]) + g2(vk["vk_beta_2"]) + g2(vk["vk_gamma_2"]) + g2(vk["vk_delta_2"]) +
+            b"".join(g1(t) for t in vk["IC"])), n_public
+
+
+class Verifier:
+    """Resident verification key on one GPU: snarkjs `groth16.verify(vk, publicSignals, proof)` for batches."""
+
+    def __init__(self, vkey, n_public=None, montgomery=True, device=0):
+        if isinstance(vkey, dict):
+            vkey, n_public = vkey_from_json(vkey)
+            montgomery = False
+        self.n_public = int(n_public)
+        self._h = C.c_void_p()
+        _check(load().g16_verifier_create(vkey, len(vkey), self.n_public, 1 if montgomery else 0, device, C.byref(self._h)))
+
+    def verify_raw(self, proofs, pubs, count):
+        """proofs: count * 256 bytes of g16_proof; pubs: count * n_public * 32 bytes -> list of bools."""
+        ok = C.create_string_buffer(max(1, count))
+        _check(load().g16_verify_batch(self._h, proofs, pubs, count, ok))
+        return [b != 0 for b in ok.raw[:count]]
+
+    def verify(self, public_signals, proof):
+        """One proof: snarkjs's signature (publicSignals as decimal strings / ints, proof as the proof.json object)."""
+        if len(public_signals) != self.n_public:
+            return False
+        return self.verify_raw(proof_from_obj(proof), b"".join(_le32(x) for x in public_signals), 1)[0]
+
+    def verify_batch(self, items):
+        """items: [(public_signals, proof_obj)] -> list of bools."""
+        bad = [len(ps) != self.n_public for ps, _ in items]
+        pr = b"".join(proof_from_obj(p) for _, p in items)
+        pub = b"".join(b"".join(_le32(x) for x in (ps if not b else [0] * self.n_public)) for (ps, _), b in zip(items, bad))
+        res = self.verify_raw(pr, pub, len(items))
+        return [r and not b for r, b in zip(res, bad)]
+
+    def timings(self):
+        ms = (C.c_float * 3)()
+        _check(load().g16_verifier_timings(self._h, ms))
+        return list(ms)
+
+    def close(self):
+        if getattr(self, "_h", None) and self._h.value:
+            load().g16_verifier_destroy(self._h)
+            self._h = C.c_void_p()
+
+    __del__ = close
+
+
+def pairing_op(pairs, device=0):
+    """[(G1 affine ints, G2 affine ((x0, x1), (y0, y1)))] -> per pair the 12 tower coordinates (ints) of the pairing
+    value the verifier kernels compute."""
+    buf = b"".join(_le32(P[0]) + _le32(P[1]) + _le32(Q[0][0]) + _le32(Q[0][1]) + _le32(Q[1][0]) + _le32(Q[1][1]) for P, Q in pairs)
+    out = C.create_string_buffer(max(1, 384 * len(pairs)))
+    _check(load().g16_pairing_op(device, buf, len(pairs), out))
+    raw = out.raw
+    return [[int.from_bytes(raw[384 * i + 32 * k:384 * i + 32 * k + 32], "little") for k in range(12)] for i in range(len(pairs))]
 
 
 def synth_witness(n_vars, n_public, n_constraints, seed, wseed):
