@@ -161,6 +161,7 @@ def batch_leg(amd, args, zkey, wtns, prover0, r, s, log):
     lens = (ctypes.c_size_t * total)(*[len(wts[i % nslots]) for i in range(total)])
     rs = (r + s) * total
     out = (amd.Proof * total)()
+    pubs = ctypes.create_string_buffer(max(1, total * args.n_public * 32))
     # reference proofs of the distinct witnesses, one at a time
     ref = []
     pr, pub = amd.Proof(), ctypes.create_string_buffer(max(1, args.n_public * 32))
@@ -170,16 +171,46 @@ def batch_leg(amd, args, zkey, wtns, prover0, r, s, log):
         ref.append(bytes(pr.a) + bytes(pr.b) + bytes(pr.c))
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    rc = lib.g16_prove_batch(prover0._h, arr, lens, total, rs, out, None)
+    rc = lib.g16_prove_batch(prover0._h, arr, lens, total, rs, out, pubs)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     assert rc == 0, lib.g16_last_error()
     for i in range(total):
         assert bytes(out[i].a) + bytes(out[i].b) + bytes(out[i].c) == ref[i % nslots], "batch proof differs from the single proof"
     log(f"batch throughput: {total} proofs by g16_prove_batch in {dt * 1e3:.1f} ms")
-    return {"proofs_per_sec": round(total / dt, 3), "proofs": total, "mode": "g16_prove_batch, 2 pipelined contexts, "
-            "witnesses uploaded from host memory inside the timed region", "distinct_witnesses": nslots,
-            "ms_per_proof": round(1e3 * dt / total, 3)}
+    res = {"proofs_per_sec": round(total / dt, 3), "proofs": total, "mode": "g16_prove_batch, 2 pipelined contexts, "
+           "witnesses uploaded from host memory inside the timed region", "distinct_witnesses": nslots,
+           "ms_per_proof": round(1e3 * dt / total, 3)}
+    return res, bytes(out), pubs.raw[:total * args.n_public * 32]
+
+
+def verify_leg(amd, args, vkey, proofs, pubs, dev, log):
+    """SURVEY 8f row 4 / north_star "every proof verifying against the reference verification key": ALL proofs of the
+    throughput leg are checked by the device batch verifier (g16_verify_batch: one verdict per proof) against the
+    verification key of the setup; one deliberately corrupted copy must come back rejected at its index."""
+    total = len(proofs) // 256
+    ver = amd.Verifier(vkey, args.n_public, montgomery=True, device=dev)
+    ver.verify_raw(proofs[:256 * min(total, 64)], pubs, min(total, 64))     # warm-up
+    best, phases = None, None
+    for _ in range(3):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        ok = ver.verify_raw(proofs, pubs, total)
+        dt = time.perf_counter() - t0
+        if best is None or dt < best:
+            best, phases = dt, ver.timings()
+    assert all(ok), f"device verifier rejected proofs {[i for i, o in enumerate(ok) if not o][:8]}"
+    k = total // 2
+    bad = bytearray(pubs)
+    bad[(k * args.n_public) * 32] ^= 1
+    ok2 = ver.verify_raw(proofs, bytes(bad), total)
+    assert ok2 == [i != k for i in range(total)], "device verifier missed the corrupted statement"
+    ver.close()
+    log(f"device verifier: {total} proofs in {best * 1e3:.1f} ms, all accepted; corrupted statement {k} rejected")
+    return {"verifications_per_sec": round(total / best, 1), "proofs": total, "ms": round(best * 1e3, 3),
+            "device_phases_ms": {"vk_x": round(phases[0], 3), "miller_loops": round(phases[1], 3), "final_exp": round(phases[2], 3)},
+            "all_accepted": True, "corrupted_statement_rejected": True,
+            "mode": "g16_verify_batch: host buffers in, one verdict per proof out (uploads inside the timed region)"}
 
 
 def main():
@@ -407,9 +438,10 @@ def main():
         t_u.sort()
         incl_upload = {"ms_per_proof_p50": round(t_u[len(t_u) // 2], 3), "proofs_per_sec": round(1e3 / t_u[len(t_u) // 2], 3),
                        "entry": "g16_prove(wtns in pageable host memory): upload + canonicity check + proof, no staging"}
-    batch = None
+    batch = verify = None
     if world == 1 and args.batch_streams > 0:
-        batch = batch_leg(amd, args, None, wtns, prover, r, s, log)
+        batch, batch_proofs, batch_pubs = batch_leg(amd, args, None, wtns, prover, r, s, log)
+        verify = verify_leg(amd, args, vkey, batch_proofs, batch_pubs, dev, log)
     if rank == 0:
         proof_obj = amd.proof_to_obj(pr)
         pub_list = [str(int.from_bytes(pub.raw[i * 32:(i + 1) * 32], "little")) for i in range(args.n_public)]
@@ -509,6 +541,7 @@ def main():
             out["value_incl_upload"] = incl_upload
         if batch is not None:
             out["batch_throughput"] = batch
+            out["batch_verify"] = verify
         if replicas is not None:
             out["replicas_throughput"] = replicas
         if world == 1 and not args.no_cpu:

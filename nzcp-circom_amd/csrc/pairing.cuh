@@ -50,6 +50,16 @@ struct PairingConsts {
 
 // ------------------------------------------------------------------ Fq2 helpers
 using F2 = Fq2Ops;
+// The Fq2 product is the unit of code here: ~1.6 k instructions, CALLED from the tower arithmetic and the curve steps
+// (inlined everywhere, the verifier's translation unit was ~2 M instructions and took a quarter of an hour to
+// compile; the call costs a few dozen cycles per 1.6 k-instruction body).  The Fq12 operations are calls as well.
+#if defined(__HIPCC__)
+#define G16_F12_FN __host__ __device__ __noinline__
+#else
+#define G16_F12_FN inline
+#endif
+G16_F12_FN Fq2 f2m(const Fq2& a, const Fq2& b) { return Fq2Ops::mul(a, b); }
+G16_F12_FN Fq2 f2s(const Fq2& a) { return Fq2Ops::sqr(a); }
 G16_HD Fq2 f2_conj(const Fq2& a) { return Fq2{a.a, fp_neg(a.b)}; }
 G16_HD Fq2 f2_dbl(const Fq2& a) { return F2::add(a, a); }
 G16_HD Fq2 f2_mul_xi(const Fq2& a) {   // (a + b u)(9 + u) = (9a - b) + (9b + a) u
@@ -70,21 +80,21 @@ G16_HD bool f6_is_zero(const Fq6& a) { return F2::is_zero(a.c0) && F2::is_zero(a
 G16_HD bool f6_eq(const Fq6& a, const Fq6& b) { return F2::eq(a.c0, b.c0) && F2::eq(a.c1, b.c1) && F2::eq(a.c2, b.c2); }
 // Karatsuba over Fq2: 6 products
 G16_HD Fq6 f6_mul(const Fq6& a, const Fq6& b) {
-  const Fq2 v0 = F2::mul(a.c0, b.c0), v1 = F2::mul(a.c1, b.c1), v2 = F2::mul(a.c2, b.c2);
-  const Fq2 t12 = F2::sub(F2::sub(F2::mul(F2::add(a.c1, a.c2), F2::add(b.c1, b.c2)), v1), v2);   // a1 b2 + a2 b1
-  const Fq2 t01 = F2::sub(F2::sub(F2::mul(F2::add(a.c0, a.c1), F2::add(b.c0, b.c1)), v0), v1);   // a0 b1 + a1 b0
-  const Fq2 t02 = F2::sub(F2::sub(F2::mul(F2::add(a.c0, a.c2), F2::add(b.c0, b.c2)), v0), v2);   // a0 b2 + a2 b0
+  const Fq2 v0 = f2m(a.c0, b.c0), v1 = f2m(a.c1, b.c1), v2 = f2m(a.c2, b.c2);
+  const Fq2 t12 = F2::sub(F2::sub(f2m(F2::add(a.c1, a.c2), F2::add(b.c1, b.c2)), v1), v2);   // a1 b2 + a2 b1
+  const Fq2 t01 = F2::sub(F2::sub(f2m(F2::add(a.c0, a.c1), F2::add(b.c0, b.c1)), v0), v1);   // a0 b1 + a1 b0
+  const Fq2 t02 = F2::sub(F2::sub(f2m(F2::add(a.c0, a.c2), F2::add(b.c0, b.c2)), v0), v2);   // a0 b2 + a2 b0
   return Fq6{F2::add(v0, f2_mul_xi(t12)), F2::add(t01, f2_mul_xi(v2)), F2::add(t02, v1)};
 }
 G16_HD Fq6 f6_sqr(const Fq6& a) { return f6_mul(a, a); }
 G16_HD Fq6 f6_inv(const Fq6& a) {
   // c0 = a0^2 - xi a1 a2, c1 = xi a2^2 - a0 a1, c2 = a1^2 - a0 a2;  1/a = (c0, c1, c2) / (a0 c0 + xi (a2 c1 + a1 c2))
-  const Fq2 c0 = F2::sub(F2::sqr(a.c0), f2_mul_xi(F2::mul(a.c1, a.c2)));
-  const Fq2 c1 = F2::sub(f2_mul_xi(F2::sqr(a.c2)), F2::mul(a.c0, a.c1));
-  const Fq2 c2 = F2::sub(F2::sqr(a.c1), F2::mul(a.c0, a.c2));
-  const Fq2 t = F2::add(F2::mul(a.c0, c0), f2_mul_xi(F2::add(F2::mul(a.c2, c1), F2::mul(a.c1, c2))));
+  const Fq2 c0 = F2::sub(f2s(a.c0), f2_mul_xi(f2m(a.c1, a.c2)));
+  const Fq2 c1 = F2::sub(f2_mul_xi(f2s(a.c2)), f2m(a.c0, a.c1));
+  const Fq2 c2 = F2::sub(f2s(a.c1), f2m(a.c0, a.c2));
+  const Fq2 t = F2::add(f2m(a.c0, c0), f2_mul_xi(F2::add(f2m(a.c2, c1), f2m(a.c1, c2))));
   const Fq2 ti = F2::inv(t);
-  return Fq6{F2::mul(c0, ti), F2::mul(c1, ti), F2::mul(c2, ti)};
+  return Fq6{f2m(c0, ti), f2m(c1, ti), f2m(c2, ti)};
 }
 
 // ------------------------------------------------------------------ Fq12
@@ -92,11 +102,6 @@ G16_HD Fq12 f12_one() { return Fq12{f6_one(), f6_zero()}; }
 G16_HD bool f12_eq(const Fq12& a, const Fq12& b) { return f6_eq(a.c0, b.c0) && f6_eq(a.c1, b.c1); }
 G16_HD bool f12_is_one(const Fq12& a) { return f12_eq(a, f12_one()); }
 G16_HD Fq12 f12_conj(const Fq12& a) { return Fq12{a.c0, f6_neg(a.c1)}; }   // = a^(p^6); the inverse on the cyclotomic subgroup
-#if defined(__HIPCC__)
-#define G16_F12_FN __host__ __device__ __noinline__   // the tower products are called, not inlined: ~30 k instructions each
-#else
-#define G16_F12_FN inline
-#endif
 G16_F12_FN Fq12 f12_mul(const Fq12& a, const Fq12& b) {
   const Fq6 v0 = f6_mul(a.c0, b.c0), v1 = f6_mul(a.c1, b.c1);
   const Fq6 s = f6_mul(f6_add(a.c0, a.c1), f6_add(b.c0, b.c1));
@@ -113,18 +118,18 @@ G16_F12_FN Fq12 f12_mul_line(const Fq12& a, const Fq2& l0, const Fq2& l3, const 
   const Fq6& x = a.c0;
   const Fq6& y = a.c1;
   // x * b0
-  const Fq2 x0l0 = F2::mul(x.c0, l0), x1l0 = F2::mul(x.c1, l0), x2l0 = F2::mul(x.c2, l0);
-  const Fq2 x0l4 = F2::mul(x.c0, l4), x1l4 = F2::mul(x.c1, l4), x2l4 = F2::mul(x.c2, l4);
+  const Fq2 x0l0 = f2m(x.c0, l0), x1l0 = f2m(x.c1, l0), x2l0 = f2m(x.c2, l0);
+  const Fq2 x0l4 = f2m(x.c0, l4), x1l4 = f2m(x.c1, l4), x2l4 = f2m(x.c2, l4);
   // (x0 + x1 V + x2 V^2)(l0 + l4 V^2) = x0 l0 + xi x1 l4 + (x1 l0 + xi x2 l4) V + (x2 l0 + x0 l4) V^2
   const Fq6 v0{F2::add(x0l0, f2_mul_xi(x1l4)), F2::add(x1l0, f2_mul_xi(x2l4)), F2::add(x2l0, x0l4)};
   // y * b1 = (y0 + y1 V + y2 V^2) l3 V = xi y2 l3 + y0 l3 V + y1 l3 V^2
-  const Fq2 y0l3 = F2::mul(y.c0, l3), y1l3 = F2::mul(y.c1, l3), y2l3 = F2::mul(y.c2, l3);
+  const Fq2 y0l3 = f2m(y.c0, l3), y1l3 = f2m(y.c1, l3), y2l3 = f2m(y.c2, l3);
   const Fq6 v1{f2_mul_xi(y2l3), y0l3, y1l3};
   // x * b1 and y * b0 for the W coefficient
-  const Fq2 x0l3 = F2::mul(x.c0, l3), x1l3 = F2::mul(x.c1, l3), x2l3 = F2::mul(x.c2, l3);
+  const Fq2 x0l3 = f2m(x.c0, l3), x1l3 = f2m(x.c1, l3), x2l3 = f2m(x.c2, l3);
   const Fq6 xb1{f2_mul_xi(x2l3), x0l3, x1l3};
-  const Fq2 y0l0 = F2::mul(y.c0, l0), y1l0 = F2::mul(y.c1, l0), y2l0 = F2::mul(y.c2, l0);
-  const Fq2 y0l4 = F2::mul(y.c0, l4), y1l4 = F2::mul(y.c1, l4), y2l4 = F2::mul(y.c2, l4);
+  const Fq2 y0l0 = f2m(y.c0, l0), y1l0 = f2m(y.c1, l0), y2l0 = f2m(y.c2, l0);
+  const Fq2 y0l4 = f2m(y.c0, l4), y1l4 = f2m(y.c1, l4), y2l4 = f2m(y.c2, l4);
   const Fq6 yb0{F2::add(y0l0, f2_mul_xi(y1l4)), F2::add(y1l0, f2_mul_xi(y2l4)), F2::add(y2l0, y0l4)};
   return Fq12{f6_add(v0, f6_mul_v(v1)), f6_add(xb1, yb0)};
 }
@@ -136,7 +141,7 @@ G16_F12_FN Fq12 f12_inv(const Fq12& a) {
 G16_F12_FN Fq12 f12_frob(const Fq12& a, int k, const PairingConsts& pc) {
   const Fq2* g = k == 1 ? pc.frob1 : (k == 2 ? pc.frob2 : pc.frob3);
   const bool cj = (k & 1) != 0;
-  auto m = [&](const Fq2& x, int i) { return F2::mul(cj ? f2_conj(x) : x, g[i]); };
+  auto m = [&](const Fq2& x, int i) { return f2m(cj ? f2_conj(x) : x, g[i]); };
   // W^0, W^2, W^4 live in c0 = (., V, V^2); W^1, W^3, W^5 in c1
   return Fq12{Fq6{m(a.c0.c0, 0), m(a.c0.c1, 2), m(a.c0.c2, 4)}, Fq6{m(a.c1.c0, 1), m(a.c1.c1, 3), m(a.c1.c2, 5)}};
 }
@@ -154,38 +159,38 @@ G16_F12_FN Fq12 f12_pow_z(const Fq12& a) {
 struct G2Proj { Fq2 x, y, z; };
 
 G16_HD void g2_double_step(G2Proj& r, EllCoeffs& c, const PairingConsts& pc) {
-  const Fq2 A = f2_mul_fq(F2::mul(r.x, r.y), pc.two_inv);
-  const Fq2 B = F2::sqr(r.y);
-  const Fq2 C = F2::sqr(r.z);
+  const Fq2 A = f2_mul_fq(f2m(r.x, r.y), pc.two_inv);
+  const Fq2 B = f2s(r.y);
+  const Fq2 C = f2s(r.z);
   const Fq2 D = F2::add(f2_dbl(C), C);
-  const Fq2 E = F2::mul(pc.twist_b, D);
+  const Fq2 E = f2m(pc.twist_b, D);
   const Fq2 F = F2::add(f2_dbl(E), E);
   const Fq2 G = f2_mul_fq(F2::add(B, F), pc.two_inv);
-  const Fq2 H = F2::sub(F2::sqr(F2::add(r.y, r.z)), F2::add(B, C));
+  const Fq2 H = F2::sub(f2s(F2::add(r.y, r.z)), F2::add(B, C));
   const Fq2 I = F2::sub(E, B);
-  const Fq2 J = F2::sqr(r.x);
-  const Fq2 E2 = F2::sqr(E);
-  r.x = F2::mul(A, F2::sub(B, F));
-  r.y = F2::sub(F2::sqr(G), F2::add(f2_dbl(E2), E2));
-  r.z = F2::mul(B, H);
+  const Fq2 J = f2s(r.x);
+  const Fq2 E2 = f2s(E);
+  r.x = f2m(A, F2::sub(B, F));
+  r.y = F2::sub(f2s(G), F2::add(f2_dbl(E2), E2));
+  r.z = f2m(B, H);
   c.l0 = f2_mul_xi(I);
   c.lVW = F2::neg(H);
   c.lVV = F2::add(f2_dbl(J), J);
 }
 
 G16_HD void g2_add_step(G2Proj& r, const Affine<Fq2Ops>& q, EllCoeffs& c) {
-  const Fq2 D = F2::sub(r.x, F2::mul(q.x, r.z));
-  const Fq2 E = F2::sub(r.y, F2::mul(q.y, r.z));
-  const Fq2 F = F2::sqr(D);
-  const Fq2 G = F2::sqr(E);
-  const Fq2 H = F2::mul(D, F);
-  const Fq2 I = F2::mul(r.x, F);
-  const Fq2 J = F2::sub(F2::add(H, F2::mul(r.z, G)), f2_dbl(I));
+  const Fq2 D = F2::sub(r.x, f2m(q.x, r.z));
+  const Fq2 E = F2::sub(r.y, f2m(q.y, r.z));
+  const Fq2 F = f2s(D);
+  const Fq2 G = f2s(E);
+  const Fq2 H = f2m(D, F);
+  const Fq2 I = f2m(r.x, F);
+  const Fq2 J = F2::sub(F2::add(H, f2m(r.z, G)), f2_dbl(I));
   const Fq2 y1 = r.y;
-  r.x = F2::mul(D, J);
-  r.y = F2::sub(F2::mul(E, F2::sub(I, J)), F2::mul(H, y1));
-  r.z = F2::mul(r.z, H);
-  c.l0 = f2_mul_xi(F2::sub(F2::mul(E, q.x), F2::mul(D, q.y)));
+  r.x = f2m(D, J);
+  r.y = F2::sub(f2m(E, F2::sub(I, J)), f2m(H, y1));
+  r.z = f2m(r.z, H);
+  c.l0 = f2_mul_xi(F2::sub(f2m(E, q.x), f2m(D, q.y)));
   c.lVV = F2::neg(E);
   c.lVW = D;
 }
@@ -193,8 +198,8 @@ G16_HD void g2_add_step(G2Proj& r, const Affine<Fq2Ops>& q, EllCoeffs& c) {
 // pi(Q) on the twist: (conj(x) xi^((p-1)/3), conj(y) xi^((p-1)/2))
 G16_HD Affine<Fq2Ops> g2_frob(const Affine<Fq2Ops>& q, const PairingConsts& pc) {
   Affine<Fq2Ops> r;
-  r.x = F2::mul(f2_conj(q.x), pc.frob1[2]);
-  r.y = F2::mul(f2_conj(q.y), pc.frob1[3]);
+  r.x = f2m(f2_conj(q.x), pc.frob1[2]);
+  r.y = f2m(f2_conj(q.y), pc.frob1[3]);
   return r;
 }
 
@@ -305,15 +310,15 @@ G16_HD bool g1_on_curve(const Affine<FqOps>& p) {
   return fp_eq(fp_sqr(p.y), fp_add(fp_mul(fp_sqr(p.x), p.x), three));
 }
 G16_HD bool g2_on_curve(const Affine<Fq2Ops>& q, const PairingConsts& pc) {
-  return F2::eq(F2::sqr(q.y), F2::add(F2::mul(F2::sqr(q.x), q.x), pc.twist_b));
+  return F2::eq(f2s(q.y), F2::add(f2m(f2s(q.x), q.x), pc.twist_b));
 }
 
 // ------------------------------------------------------------------ host-only: the constants
 inline Fq2 f2_pow_words(const Fq2& a, const uint32_t* e, int nwords) {
   Fq2 r = F2::one();
   for (int i = nwords * 32 - 1; i >= 0; i--) {
-    r = F2::sqr(r);
-    if ((e[i >> 5] >> (i & 31)) & 1) r = F2::mul(r, a);
+    r = f2s(r);
+    if ((e[i >> 5] >> (i & 31)) & 1) r = f2m(r, a);
   }
   return r;
 }
@@ -339,10 +344,10 @@ inline void pairing_consts_init(PairingConsts& pc) {
   const Fq2 xi{nine, one};
   const Fq2 g1 = f2_pow_words(xi, e, 8);                   // xi^((p-1)/6)
   pc.frob1[0] = F2::one();
-  for (int k = 1; k < 6; k++) pc.frob1[k] = F2::mul(pc.frob1[k - 1], g1);
+  for (int k = 1; k < 6; k++) pc.frob1[k] = f2m(pc.frob1[k - 1], g1);
   for (int k = 0; k < 6; k++) {
-    pc.frob2[k] = F2::mul(pc.frob1[k], f2_conj(pc.frob1[k]));
-    pc.frob3[k] = F2::mul(pc.frob2[k], pc.frob1[k]);
+    pc.frob2[k] = f2m(pc.frob1[k], f2_conj(pc.frob1[k]));
+    pc.frob3[k] = f2m(pc.frob2[k], pc.frob1[k]);
   }
   pc.twist_b = Fq2{Fq{G16_G2B_C0}, Fq{G16_G2B_C1}};
   pc.two_inv = fp_inv(fp_add(one, one));
