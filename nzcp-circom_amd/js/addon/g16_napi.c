@@ -13,6 +13,9 @@
  *           info(handle) -> {nVars, nPublic, domainSize, nCoefs}
  *           timings(handle) -> {...ms}
  *           destroy(handle)
+ *           createVerifier(vkey: Buffer, nPublic, montgomery: 0|1, device) -> Promise<vhandle>   (g16_verifier_create)
+ *           verifyBatch(vhandle, proofs: Buffer(count*256), pubs: Buffer(count*nPublic*32)) -> Promise<Buffer(count)>
+ *           destroyVerifier(vhandle)
  */
 #include <node_api.h>
 #include <stdlib.h>
@@ -351,6 +354,147 @@ static napi_value js_destroy(napi_env env, napi_callback_info info) {
   return NULL;
 }
 
+/* ------------------------------------------------------------------ verifier (g16_verifier_*): snarkjs groth16.verify */
+typedef struct {
+  g16_verifier* v;
+  uint32_t n_public;
+  uint32_t inflight;
+  int closing;
+} vhandle_t;
+
+static void vhandle_finalize(napi_env env, void* data, void* hint) {
+  vhandle_t* h = (vhandle_t*)data;
+  if (h->v) g16_verifier_destroy(h->v);
+  free(h);
+}
+
+typedef struct {
+  napi_async_work work;
+  napi_deferred deferred;
+  napi_ref refs[3];
+  int nrefs;
+  int kind;                 /* 0 = create, 1 = verify */
+  const uint8_t* vkey; size_t vkey_len; uint32_t n_public; int montgomery, device; g16_verifier* created;
+  vhandle_t* h; const uint8_t* proofs; const uint8_t* pubs; size_t count; uint8_t* ok;
+  int rc; char err[512];
+} vjob_t;
+
+static void vjob_execute(napi_env env, void* data) {
+  vjob_t* j = (vjob_t*)data;
+  if (j->kind == 0) j->rc = g16_verifier_create(j->vkey, j->vkey_len, j->n_public, j->montgomery, j->device, &j->created);
+  else j->rc = g16_verify_batch(j->h->v, (const g16_proof*)j->proofs, j->pubs, j->count, j->ok);
+  if (j->rc) {
+    strncpy(j->err, g16_last_error(), sizeof(j->err) - 1);
+    j->err[sizeof(j->err) - 1] = 0;
+  }
+}
+
+static void vjob_complete(napi_env env, napi_status status, void* data) {
+  vjob_t* j = (vjob_t*)data;
+  napi_value result;
+  if (status != napi_ok || j->rc) {
+    napi_value msg, err;
+    napi_create_string_utf8(env, j->rc ? j->err : "g16 addon: async work cancelled", NAPI_AUTO_LENGTH, &msg);
+    napi_create_error(env, NULL, msg, &err);
+    napi_reject_deferred(env, j->deferred, err);
+  } else if (j->kind == 0) {
+    vhandle_t* h = (vhandle_t*)calloc(1, sizeof(vhandle_t));
+    h->v = j->created;
+    h->n_public = j->n_public;
+    napi_create_external(env, h, vhandle_finalize, NULL, &result);
+    napi_resolve_deferred(env, j->deferred, result);
+  } else {
+    void* dst;
+    napi_create_buffer_copy(env, j->count, j->ok, &dst, &result);
+    napi_resolve_deferred(env, j->deferred, result);
+  }
+  if (j->h) {
+    j->h->inflight--;
+    if (j->h->closing && j->h->inflight == 0 && j->h->v) { g16_verifier_destroy(j->h->v); j->h->v = NULL; }
+  }
+  for (int i = 0; i < j->nrefs; i++) napi_delete_reference(env, j->refs[i]);
+  napi_delete_async_work(env, j->work);
+  free(j->ok);
+  free(j);
+}
+
+static napi_value queue_vjob(napi_env env, vjob_t* j, const char* name) {
+  napi_value promise, resname;
+  NAPI_OK(napi_create_promise(env, &j->deferred, &promise));
+  NAPI_OK(napi_create_string_utf8(env, name, NAPI_AUTO_LENGTH, &resname));
+  NAPI_OK(napi_create_async_work(env, NULL, resname, vjob_execute, vjob_complete, j, &j->work));
+  NAPI_OK(napi_queue_async_work(env, j->work));
+  return promise;
+}
+
+static napi_value js_create_verifier(napi_env env, napi_callback_info info) {
+  size_t argc = 4;
+  napi_value argv[4];
+  bool isbuf = false;
+  NAPI_OK(napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
+  if (argc < 4 || napi_is_buffer(env, argv[0], &isbuf) != napi_ok || !isbuf) {
+    napi_throw_type_error(env, NULL, "createVerifier(vkey: Buffer, nPublic, montgomery, device)");
+    return NULL;
+  }
+  vjob_t* j = (vjob_t*)calloc(1, sizeof(vjob_t));
+  void* data;
+  int32_t mont = 0, dev = 0;
+  NAPI_OK(napi_get_buffer_info(env, argv[0], &data, &j->vkey_len));
+  j->vkey = (const uint8_t*)data;
+  NAPI_OK(napi_get_value_uint32(env, argv[1], &j->n_public));
+  NAPI_OK(napi_get_value_int32(env, argv[2], &mont));
+  NAPI_OK(napi_get_value_int32(env, argv[3], &dev));
+  j->montgomery = mont;
+  j->device = dev;
+  NAPI_OK(napi_create_reference(env, argv[0], 1, &j->refs[j->nrefs++]));
+  return queue_vjob(env, j, "g16_verifier_create");
+}
+
+static napi_value js_verify_batch(napi_env env, napi_callback_info info) {
+  size_t argc = 3;
+  napi_value argv[3];
+  vhandle_t* h = NULL;
+  bool b1 = false, b2 = false;
+  NAPI_OK(napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
+  if (argc < 3 || napi_get_value_external(env, argv[0], (void**)&h) != napi_ok || !h || !h->v || h->closing ||
+      napi_is_buffer(env, argv[1], &b1) != napi_ok || !b1 || napi_is_buffer(env, argv[2], &b2) != napi_ok || !b2) {
+    napi_throw_type_error(env, NULL, "verifyBatch(vhandle, proofs: Buffer, pubs: Buffer)");
+    return NULL;
+  }
+  void *pd, *ud;
+  size_t plen, ulen;
+  NAPI_OK(napi_get_buffer_info(env, argv[1], &pd, &plen));
+  NAPI_OK(napi_get_buffer_info(env, argv[2], &ud, &ulen));
+  if (plen % sizeof(g16_proof) || ulen != (plen / sizeof(g16_proof)) * (size_t)h->n_public * 32) {
+    napi_throw_range_error(env, NULL, "verifyBatch: proofs must be count*256 bytes and pubs count*nPublic*32 bytes");
+    return NULL;
+  }
+  vjob_t* j = (vjob_t*)calloc(1, sizeof(vjob_t));
+  j->kind = 1;
+  j->h = h;
+  j->proofs = (const uint8_t*)pd;
+  j->pubs = (const uint8_t*)ud;
+  j->count = plen / sizeof(g16_proof);
+  j->ok = (uint8_t*)calloc(j->count ? j->count : 1, 1);
+  h->inflight++;
+  NAPI_OK(napi_create_reference(env, argv[0], 1, &j->refs[j->nrefs++]));
+  NAPI_OK(napi_create_reference(env, argv[1], 1, &j->refs[j->nrefs++]));
+  NAPI_OK(napi_create_reference(env, argv[2], 1, &j->refs[j->nrefs++]));
+  return queue_vjob(env, j, "g16_verify_batch");
+}
+
+static napi_value js_destroy_verifier(napi_env env, napi_callback_info info) {
+  size_t argc = 1;
+  napi_value argv[1];
+  vhandle_t* h = NULL;
+  NAPI_OK(napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
+  if (argc >= 1 && napi_get_value_external(env, argv[0], (void**)&h) == napi_ok && h && h->v) {
+    h->closing = 1;
+    if (h->inflight == 0) { g16_verifier_destroy(h->v); h->v = NULL; }
+  }
+  return NULL;
+}
+
 static napi_value init(napi_env env, napi_value exports) {
   napi_property_descriptor props[] = {
       {"create", NULL, js_create, NULL, NULL, NULL, napi_default, NULL},
@@ -359,6 +503,9 @@ static napi_value init(napi_env env, napi_value exports) {
       {"info", NULL, js_info, NULL, NULL, NULL, napi_default, NULL},
       {"timings", NULL, js_timings, NULL, NULL, NULL, napi_default, NULL},
       {"destroy", NULL, js_destroy, NULL, NULL, NULL, napi_default, NULL},
+      {"createVerifier", NULL, js_create_verifier, NULL, NULL, NULL, napi_default, NULL},
+      {"verifyBatch", NULL, js_verify_batch, NULL, NULL, NULL, napi_default, NULL},
+      {"destroyVerifier", NULL, js_destroy_verifier, NULL, NULL, NULL, napi_default, NULL},
   };
   NAPI_OK(napi_define_properties(env, exports, sizeof(props) / sizeof(props[0]), props));
   return exports;

@@ -2,6 +2,8 @@
 // CLI twin of `snarkjs groth16 prove <circuit.zkey> <witness.wtns> <proof.json> <public.json>`
 // (snarkjs cli.js groth16Prove [EXT]; the reference's Makefile scripts the sibling PLONK lines,
 // /root/reference/Makefile:30-33).  Writes JSON.stringify(x, null, 1) like snarkjs.
+// And of `snarkjs groth16 verify <verification_key.json> <public.json> <proof.json>` (groth16Verify [EXT]): prints
+// "[INFO]  snarkJS: OK!" and exits 0, or "[ERROR] snarkJS: Invalid proof" and exits 1.
 "use strict";
 const fs = require("fs");
 const { groth16 } = require("./index.js");
@@ -9,6 +11,16 @@ const { groth16 } = require("./index.js");
 async function main(argv) {
   let a = argv.slice(2);
   if (a[0] === "groth16") a = a.slice(1);
+  if (a[0] === "verify") {
+    const pos = a.slice(1).filter((x) => !x.startsWith("--"));
+    const di = a.indexOf("--device");
+    const [vk = "verification_key.json", pub = "public.json", proof = "proof.json"] = pos.filter((x, i) => di < 0 || a.indexOf(x) !== di + 1);
+    const ok = await groth16.verify(JSON.parse(fs.readFileSync(vk, "utf-8")), JSON.parse(fs.readFileSync(pub, "utf-8")),
+      JSON.parse(fs.readFileSync(proof, "utf-8")), { device: di >= 0 ? parseInt(a[di + 1], 10) : 0 });
+    if (!ok) throw new Error("Invalid proof");
+    console.log("[INFO]  snarkJS: OK!");
+    return;
+  }
   if (a[0] === "prove") a = a.slice(1);
   const opts = {};
   const pos = [];

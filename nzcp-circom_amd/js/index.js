@@ -8,6 +8,8 @@
 // proof / publicSignals have exactly snarkjs's shape (decimal strings; key order pi_a, pi_b, pi_c,
 // protocol, curve), so JSON.stringify(x, null, 1) reproduces proof.json / public.json byte for byte
 // given the same blinding (r, s).  Errors are thrown Errors with snarkjs's messages.
+// groth16.verify(vk, publicSignals, proof) is snarkjs's too (GPU pairing check, csrc/verify.hip); createVerifier(vk)
+// keeps the key resident and verifies batches, one verdict per proof.
 // Extensions (not in snarkjs): opts = {r, s, device, devices, windowBits}; groth16.createProver() keeps the
 // proving key resident in HBM across proofs; prover.proveBatch(wtnsList); createProver(zkey, {devices: [0, 1, ...]})
 // shards ONE proof over several GPUs of the node (BASELINE config 4: MSM point ranges + the A/B/C evaluation split
@@ -123,7 +125,60 @@ async function createProver(zkey, opts = {}) {
   return new Prover(h);
 }
 
+// ------------------------------------------------------------------ verifier (snarkjs groth16.verify, batched on the GPU)
+function le32(v) {
+  let n = BigInt(v);
+  if (n < 0n) throw new Error("negative field element");
+  const out = Buffer.alloc(32);
+  for (let i = 0; i < 32; i++) { out[i] = Number(n & 0xffn); n >>= 8n; }
+  return out;   // (values >= 2^256 are cut: no field element is that large)
+}
+function g1Bytes(t) { return String(t[2]) === "0" ? Buffer.alloc(64) : Buffer.concat([le32(t[0]), le32(t[1])]); }
+function g2Bytes(t) {
+  if (String(t[2][0]) === "0" && String(t[2][1]) === "0") return Buffer.alloc(128);
+  return Buffer.concat([le32(t[0][0]), le32(t[0][1]), le32(t[1][0]), le32(t[1][1])]);
+}
+// proof.json object -> g16_proof bytes; verification_key.json object -> the C ABI's point image (standard form)
+function proofBytes(p) { return Buffer.concat([g1Bytes(p.pi_a), g2Bytes(p.pi_b), g1Bytes(p.pi_c)]); }
+function vkeyBytes(vk) {
+  if (!vk || vk.protocol !== "groth16" || !Array.isArray(vk.IC) || vk.IC.length !== Number(vk.nPublic) + 1)
+    throw new Error("verification key: not a groth16 key (protocol / IC / nPublic)");
+  return Buffer.concat([g1Bytes(vk.vk_alpha_1), g2Bytes(vk.vk_beta_2), g2Bytes(vk.vk_gamma_2), g2Bytes(vk.vk_delta_2),
+    ...vk.IC.map(g1Bytes)]);
+}
+
+class Verifier {
+  constructor(handle, nPublic) { this._h = handle; this.nPublic = nPublic; }
+  // items: [{publicSignals, proof}] -> Promise<boolean[]>, one verdict per proof (g16_verify_batch)
+  async verifyBatch(items) {
+    if (!this._h) throw new Error("verifier is closed");
+    const short = items.map((it) => it.publicSignals.length !== this.nPublic);
+    const proofs = Buffer.concat(items.map((it) => proofBytes(it.proof)));
+    const pubs = Buffer.concat(items.map((it, i) => (short[i] ? Buffer.alloc(this.nPublic * 32)
+      : Buffer.concat(it.publicSignals.map(le32)))));
+    const ok = await native().verifyBatch(this._h, proofs, pubs);
+    return items.map((_, i) => !short[i] && ok[i] !== 0);
+  }
+  async verify(publicSignals, proof) { return (await this.verifyBatch([{ publicSignals, proof }]))[0]; }
+  close() { if (this._h) { native().destroyVerifier(this._h); this._h = null; } }
+}
+
+async function createVerifier(vk, opts = {}) {
+  const h = await native().createVerifier(vkeyBytes(vk), Number(vk.nPublic), 0, opts.device | 0);
+  return new Verifier(h, Number(vk.nPublic));
+}
+
 const groth16 = {
+  // snarkjs: groth16.verify(vk_verifier, publicSignals, proof[, logger]) -> boolean
+  async verify(vk, publicSignals, proof, opts = {}) {
+    const v = await createVerifier(vk, opts && typeof opts.debug === "function" ? {} : opts);
+    try {
+      return await v.verify(publicSignals, proof);
+    } finally {
+      v.close();
+    }
+  },
+  createVerifier,
   // snarkjs: groth16.prove(zkeyFileName, witnessFileName[, logger]) -> {proof, publicSignals}
   async prove(zkey, wtns, opts = {}) {
     if (opts && typeof opts.debug === "function") opts = { logger: opts };   // snarkjs passes a logger third
@@ -137,4 +192,4 @@ const groth16 = {
   createProver,
 };
 
-module.exports = { groth16, createProver, Prover, proofObject, publicSignals };
+module.exports = { groth16, createProver, Prover, createVerifier, Verifier, proofObject, publicSignals, proofBytes, vkeyBytes };

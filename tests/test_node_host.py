@@ -60,6 +60,65 @@ def test_cli_writes_byte_identical_json(addon, tmp_path, name):
 
 @needs_node
 @pytest.mark.gpu
+def test_node_verify_and_cli(addon, tmp_path):
+    """snarkjs `groth16.verify(vk, publicSignals, proof)` and `snarkjs groth16 verify vk.json public.json proof.json`
+    through the Node host (GPU pairing check): the golden proofs verify against the golden verification keys (both
+    written by the Python oracle), tampered statements and proofs do not; a resident verifier returns one verdict per
+    proof of a batch."""
+    meta = json.load(open(golden_path("nzcp513.json")))
+    small = json.load(open(golden_path("small.json")))
+    script = f"""
+    const {{ groth16 }} = require({json.dumps(JS)});
+    const meta = {json.dumps({k: meta[k] for k in ('vkey', 'public', 'proof')})};
+    const small = {json.dumps({k: small[k] for k in ('vkey', 'public', 'proof')})};
+    (async () => {{
+      const out = {{}};
+      out.good = await groth16.verify(meta.vkey, meta.public, meta.proof);
+      const pub2 = meta.public.slice(); pub2[7] = (BigInt(pub2[7]) + 1n).toString();
+      out.badPub = await groth16.verify(meta.vkey, pub2, meta.proof);
+      const pr2 = JSON.parse(JSON.stringify(meta.proof)); pr2.pi_c = pr2.pi_a;
+      out.badProof = await groth16.verify(meta.vkey, meta.public, pr2);
+      out.shortPub = await groth16.verify(meta.vkey, meta.public.slice(1), meta.proof);
+      out.wrongKey = await groth16.verify(small.vkey, small.public, meta.proof);
+      const v = await groth16.createVerifier(small.vkey);
+      const items = [];
+      for (let i = 0; i < 70; i++) {{
+        const ps = small.public.slice();
+        if (i % 9 === 4) ps[0] = (BigInt(ps[0]) + BigInt(i)).toString();
+        items.push({{ publicSignals: ps, proof: small.proof }});
+      }}
+      out.batch = await v.verifyBatch(items);
+      v.close();
+      let err = "none";
+      try {{ await groth16.verify({{protocol: "plonk"}}, [], meta.proof); }} catch (e) {{ err = e.message; }}
+      out.err = err;
+      console.log(JSON.stringify(out));
+    }})();
+    """
+    r = run_node(script)
+    assert r.returncode == 0, r.stderr
+    out = json.loads(r.stdout)
+    assert out["good"] is True and out["badPub"] is False and out["badProof"] is False
+    assert out["shortPub"] is False and out["wrongKey"] is False
+    assert out["batch"] == [i % 9 != 4 for i in range(70)]
+    assert "not a groth16 key" in out["err"]
+    vk, pj, uj = tmp_path / "verification_key.json", tmp_path / "proof.json", tmp_path / "public.json"
+    vk.write_text(json.dumps(meta["vkey"]))
+    pj.write_text(f.js_stringify(meta["proof"]))
+    uj.write_text(f.js_stringify(meta["public"]))
+    r = subprocess.run(["node", os.path.join(JS, "cli.js"), "groth16", "verify", str(vk), str(uj), str(pj)],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "snarkJS: OK!" in r.stdout, r.stderr
+    bad = list(meta["public"])
+    bad[0] = str(int(bad[0]) + 1)
+    uj.write_text(f.js_stringify(bad))
+    r = subprocess.run(["node", os.path.join(JS, "cli.js"), "groth16", "verify", str(vk), str(uj), str(pj)],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 1 and "Invalid proof" in r.stderr
+
+
+@needs_node
+@pytest.mark.gpu
 def test_resident_prover_and_random_blinding(addon):
     meta = json.load(open(golden_path("small.json")))
     script = f"""
