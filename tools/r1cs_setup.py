@@ -26,8 +26,11 @@ def main():
     ap.add_argument("vkey_json")
     ap.add_argument("--seed", type=int, default=0x6E7A6370)
     ap.add_argument("--threads", type=int, default=0)
+    ap.add_argument("--device", type=int, default=-1,
+                    help="run the fixed-base multiplications on this GPU (g16_setup_device); default: host threads")
     a = ap.parse_args()
     amd = entry.load_package()
+    amd.setup_device(a.device)
     data = open(a.r1cs, "rb").read()
     zkey, vkey = amd.r1cs_setup(data, a.seed, a.threads)
     n_public = None
