@@ -133,8 +133,8 @@ struct MsmGroup {
   // its QuinSelector comparisons.  Points whose scalar value is shared by >= kDupMin points of the section take one
   // entry in a "dup" row (bucket = a hash of the value; a bucket qualifies when every scalar in it is equal, checked
   // exactly) instead of one entry per window: sum_i s P_i = s (sum_i P_i).  The bucket sums T are then combined by
-  // bit position (U_b = sum of the T whose value has bit b, one shuffle tree per bit) and the host runs Horner over
-  // the 254 bit sums.  dup_rows rows of B hash buckets follow the digit (+ ones) rows of every section.
+  // 16-bit chunk of the value (a lane multiplies its T by chunk k of its value, one shuffle tree per chunk: U_k = sum
+  // chunk_k(s) T) and the host runs Horner over the 16 chunk sums.  dup_rows rows of B hash buckets follow the digit (+ ones) rows of every section.
   uint32_t dup_rows = 0;        // 0 = off
   uint32_t dup_bits = 0;        // log2(dup_rows * B) hash buckets per section
   uint32_t rps = 0, rows = 0;   // rows per section (W + ones + dup_rows), rows in total
@@ -156,7 +156,8 @@ struct MsmResult {
 };
 static constexpr uint32_t kDupMin = 8;       // points sharing a value before the dup row pays (1 entry + ~127 tree
                                              // additions per value against one entry per window)
-static constexpr uint32_t kDupBitRows = 254; // bit positions of a scalar
+static constexpr uint32_t kDupChunkBits = 16; // a repeated value is cut into chunks of this many bits ...
+static constexpr uint32_t kDupBitRows = (254 + kDupChunkBits - 1) / kDupChunkBits;   // ... one output row per chunk
 // msm_launch only enqueues: front end + G1 lane on `st`, the G2 lane (if any) forks onto `st2` after the sort
 // (st2 == nullptr or == st: same stream).  msm_collect waits for both, folds the window sums on the host
 // (Horner, c doublings per row) and fills `out`.  One launch in flight per workspace.
@@ -183,12 +184,13 @@ template <class F> inline void msm_combine_windows(XYZZ<F>& total, const XYZZ<F>
   }
   if (ones) xyzz_add(total, windows[W]);
 }
-// total += sum_b 2^b * bits[b]  (the dup rows' bit-position sums: Horner, one doubling per bit)
+// total += sum_k 2^(k L) * bits[k]  (the dup rows' chunk sums, L = kDupChunkBits: Horner, L doublings per row)
 template <class F> inline void msm_add_bit_sums(XYZZ<F>& total, const XYZZ<F>* bits) {
   XYZZ<F> acc;
   xyzz_set_inf(acc);
   for (int b = (int)kDupBitRows - 1; b >= 0; b--) {
-    if (!xyzz_is_inf(acc)) xyzz_dbl(acc);
+    if (!xyzz_is_inf(acc))
+      for (uint32_t k = 0; k < kDupChunkBits; k++) xyzz_dbl(acc);
     xyzz_add(acc, bits[b]);
   }
   xyzz_add(total, acc);

@@ -97,7 +97,7 @@ struct MsmLaneWs {
   uint32_t max_heavy = 0;
   void* d_seg = nullptr;
   void* d_red = nullptr;
-  void* d_canon = nullptr;           // `rows` canonical XYZZ row sums, then nsec_lane * 254 bit sums of the dup rows
+  void* d_canon = nullptr;           // `rows` canonical XYZZ row sums, then nsec_lane * kDupBitRows chunk sums of the dup rows
   void* d_dseg = nullptr;            // dup rows: per (section, bit, chunk of 64 hash buckets) sums
   void* d_dred = nullptr;            // ... and their tree
   hipStream_t st_dup = nullptr;      // the dup-row stage runs beside the bucket reduce of the digit rows
@@ -508,9 +508,13 @@ static __global__ __launch_bounds__(256) void msm_dup_compact_kernel(const uint3
   dlist[((size_t)sl << dup_bits) + k] = hb;
 }
 
-// Step 2: dseg[(sl * 254 + bit) * nchunk + chunk] = sum of the bucket sums T of list entries [64 chunk, +64) of
-// section sl whose (single) scalar value has bit `bit` set.  One wavefront per (sl, bit, chunk); chunks beyond the
-// list write infinity.  The tree over the chunks is msm_wave_reduce_kernel with 254 * nsec rows.
+// Step 2: dseg[(sl * kDupBitRows + k) * nchunk + chunk] = sum over the list entries [64 chunk, +64) of section sl of
+// (bits [k L, (k+1) L) of the entry's single scalar value) * (its bucket sum T), L = kDupChunkBits.  A lane multiplies
+// its own entry by the L-bit chunk (L doublings + ~L/2 additions), then one shuffle tree per wavefront; the host
+// weights row k with 2^(k L).  One wavefront per (sl, k, chunk); chunks beyond the list write infinity; the tree over
+// the chunks is msm_wave_reduce_kernel with kDupBitRows * nsec rows.  (First version: one row per BIT, a lane
+// contributing T when its value has the bit -- 254 trees per section instead of 16 short multiplications and 16
+// trees: 23 % of all VALU instructions of a proof, profiles/r02_pmc_accumulate.txt.)
 template <class F>
 __global__ __launch_bounds__(kTailThreads) void msm_dup_bits_kernel(const XYZZ<F>* __restrict__ partial,
                                                               const XYZZ<F>* __restrict__ bsum,
@@ -539,8 +543,15 @@ __global__ __launch_bounds__(kTailThreads) void msm_dup_bits_kernel(const XYZZ<F
     if (k < count) {
       const uint32_t hb = dlist[((size_t)sl << dup_bits) + k];
       const Fr v = scalars[src[dup_rep[((size_t)(sec0 + sl) << dup_bits) + hb]]];
-      if ((v.v[bit >> 5] >> (bit & 31)) & 1u)
-        acc = msm_bucket_value<F>(partial, bsum, toff, (sl * rps + dup_row0) * B + hb);
+      // this row's kDupChunkBits-bit chunk of the value times the bucket sum (short double-and-add)
+      const uint32_t pos = bit * kDupChunkBits;
+      uint64_t w2 = v.v[pos >> 5];
+      if ((pos >> 5) + 1 < 8) w2 |= (uint64_t)v.v[(pos >> 5) + 1] << 32;
+      const uint32_t cv = (uint32_t)(w2 >> (pos & 31)) & ((1u << kDupChunkBits) - 1u);
+      if (cv) {
+        const XYZZ<F> t = msm_bucket_value<F>(partial, bsum, toff, (sl * rps + dup_row0) * B + hb);
+        msm_mul_small(acc, t, cv);
+      }
     }
     for (int d = 32; d >= 1; d >>= 1) {
       const XYZZ<F> q = xyzz_shfl_down(acc, d);
@@ -676,7 +687,7 @@ int msm_launch_lane_t(const MsmGroup& g, MsmWorkspace* ws, MsmLaneWs& ln, const 
       G16_HIP(hipEventRecord(ln.ev_dup_fork, st));
       G16_HIP(hipStreamWaitEvent(sd, ln.ev_dup_fork, 0));
     }
-    // dup rows: bit-position sums of the repeated-value bucket sums (bucket keys are lane-local: section sl of the
+    // dup rows: chunk-weighted sums of the repeated-value bucket sums (bucket keys are lane-local: section sl of the
     // lane starts at row sl * rps)
     // at most kDupChunks * 64 distinct repeated values per section take this path (more are simply left out of
     // the list... they cannot be: every qualifying bucket must be summed) -> the chunk count covers all buckets
