@@ -78,6 +78,8 @@ struct MsmLaneWs {
   uint32_t rows = 0;                 // (key_hi - key_lo) / B
   uint64_t max_tasks = 0;
   uint32_t task_len = 0;             // entries per task in THIS lane (the G2 lane has fewer lanes to fill and cuts shorter)
+  uint32_t task_len_min = 0;         // shortest task length a launch may pick (sizes max_tasks)
+  uint32_t* h_stat = nullptr;        // pinned: [0] = end, [1] = start of the lane's sorted entries in the last launch
   uint32_t seg_len = 0;              // buckets per reduce segment
   uint32_t* d_off = nullptr;         // [nbk + 1] first sorted entry of a bucket (absolute position in d_sorted)
   uint32_t* d_toff = nullptr;        // [nbk + 1] exclusive scan of ceil(cnt / task_len): first task id of a bucket

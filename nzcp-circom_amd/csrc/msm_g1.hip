@@ -745,8 +745,16 @@ static int lane_create(MsmLaneWs& ln, const MsmGroup& g, int curve, uint32_t key
     while (ln.seg_len > (1u << g.salt_bits) || ((1u << g.salt_bits) % ln.seg_len) != 0) ln.seg_len >>= 1;
     if (ln.seg_len == 0) ln.seg_len = 1;
   }
+  // A launch re-derives the task length from the sorted entries the PREVIOUS launch of this workspace really had
+  // (msm_build_queue): the create-time estimate above knows the points, not the witness -- the real NZCP witness
+  // leaves ~1.5 M entries of an estimated 12.8 M after the zero / one / repeated-value classes, and 32-entry tasks
+  // then fill a fifth of the persistent grid (r02 sweep: 4.40 -> 4.18 ms per proof at 16; the synthetic witness, with
+  // its 32 % full-width scalars, wants 32: 7.9 against 9.4 ms).
+  ln.task_len_min = g.task_len_forced ? ln.task_len : 16u;   // (8 on the G2 lane: measured worse, r02 sweep)
   // every non-empty bucket has <= 1 short task + entries / task_len full ones
-  ln.max_tasks = nbk + entries / ln.task_len + 64;
+  ln.max_tasks = nbk + entries / ln.task_len_min + 64;
+  G16_HIP(hipHostMalloc((void**)&ln.h_stat, 64));
+  ln.h_stat[0] = ln.h_stat[1] = 0;
   const size_t pb = curve == 2 ? sizeof(G2XYZZ29) : sizeof(G1XYZZ29);   // device-side (lazy) points
   const size_t cpb = msm_point_bytes(curve);                             // canonical, host-visible
   const uint64_t nseg = (g.B + ln.seg_len - 1) / ln.seg_len;
@@ -802,6 +810,7 @@ static void lane_destroy(MsmLaneWs& ln) {
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   if (ln.h_pinned) (void)hipHostFree(ln.h_pinned);
+  if (ln.h_stat) (void)hipHostFree(ln.h_stat);
   if (ln.st_dup) (void)hipStreamDestroy(ln.st_dup);
   hipEvent_t evs[] = {ln.ev0, ln.ev1, ln.ev_done, ln.trace_ev[0], ln.trace_ev[1], ln.trace_ev[2], ln.trace_ev[3],
                       ln.ev_dup_fork, ln.ev_dup_join};
@@ -898,11 +907,18 @@ int msm_build_queue(const MsmGroup& g, MsmWorkspace* ws, MsmLaneWs& ln, hipStrea
   // the lane's first entry = the start of the first bin of its first row
   const uint32_t* off_base = ws->d_bin_start + (size_t)(ln.key_lo / g.B) * g.bins;
   const uint32_t ntiles = (nbk + kScanTile - 1) / kScanTile;
+  if (!g.task_len_forced && ln.h_stat[0] > ln.h_stat[1]) {   // entries of the previous launch (its copies completed
+    const uint64_t e = ln.h_stat[0] - ln.h_stat[1];          // before msm_collect returned): one task per lane of the
+    const uint64_t t = e / (ln.curve == 2 ? 131072u : 262144u);   // persistent grid, within [min, 32]
+    ln.task_len = (uint32_t)(t < ln.task_len_min ? ln.task_len_min : (t > 32 ? 32 : t));
+  }
   msm_scan_tiles_kernel<<<ntiles, 256, 0, st>>>(cnt, nbk, ln.task_len, ln.d_tile_a, ln.d_tile_b, ln.d_tile_c);
   msm_scan_top_kernel<<<1, 1024, 0, st>>>(ln.d_tile_a, ln.d_tile_b, ln.d_tile_c, ntiles, off_base, ln.d_off + nbk,
                                           ln.d_toff + nbk, ln.d_foff + nbk);
   msm_scan_apply_kernel<<<ntiles, 256, 0, st>>>(cnt, nbk, ln.task_len, ln.d_tile_a, ln.d_tile_b, ln.d_tile_c, off_base,
                                                 ln.d_off, ln.d_toff, ln.d_foff);
+  G16_HIP(hipMemcpyAsync(&ln.h_stat[0], ln.d_off + nbk, 4, hipMemcpyDeviceToHost, st));
+  G16_HIP(hipMemcpyAsync(&ln.h_stat[1], ln.d_off, 4, hipMemcpyDeviceToHost, st));
   G16_HIP(hipMemsetAsync(ln.d_class, 0, 2 * kRemClasses * 4, st));
   msm_rem_count_kernel<<<(nbk + 255) / 256, 256, 0, st>>>(cnt, nbk, ln.task_len, ln.d_class);
   msm_task_fill_kernel<<<(nbk + 255) / 256, 256, 0, st>>>(ln.d_off, ln.d_toff, ln.d_foff, nbk, ln.task_len, ln.d_task_desc,
