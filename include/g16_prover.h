@@ -284,6 +284,37 @@ void g16_verifier_destroy(g16_verifier* v);
  * kernels compute, as the coefficients (c0, c1) of W^0..W^5 in the tower Fq12 = Fq2[W]/(W^6 - (9+u)). */
 int g16_pairing_op(int device, const uint8_t* in, uint32_t count, uint8_t* out);
 
+/* ---------------------------------------------------------------------------------------------------------------
+ * PLONK prover on the device.  [EXT] snarkjs 0.4.12 plonk_prove.js `plonk.prove(zkey, wtns)` -- the
+ * protocol whose setup the reference scripts (/root/reference/Makefile:30-33: `snarkjs plonk setup`, `zkey export
+ * verificationkey`, `zkey export solidityverifier`).  zkey: a PLONK .zkey as `snarkjs plonk setup` writes it (protocol
+ * id 2; the Lagrange section 13 is not read).  Errors carry snarkjs's texts: "zkey file is not plonk" (snarkjs's own
+ * text says "groth16" there), "Invalid witness length. Circuit: N, witness: M, A", "Copy constraints does not match",
+ * "T Polynomial is not divisible", "Polinomial does not divide".
+ * blinding: nine 32-byte LE scalars b1..b9 below r (snarkjs: Fr.random() each), or NULL for the OS CSPRNG -- with the
+ * same nine scalars the proof is reproducible byte for byte.
+ * proof: points affine in standard form (x | y, infinity = zeros), evaluations as standard-form integers: the fields of
+ * snarkjs's proof.json in its key order.  pub receives n_public * 32 bytes.  No CPU path (G16_E_NOGPU). */
+typedef struct g16_plonk g16_plonk;
+typedef struct g16_plonk_proof {
+  uint8_t A[64], B[64], C[64], Z[64], T1[64], T2[64], T3[64];
+  uint8_t eval_a[32], eval_b[32], eval_c[32], eval_s1[32], eval_s2[32], eval_zw[32], eval_r[32];
+  uint8_t Wxi[64], Wxiw[64];
+} g16_plonk_proof;
+int g16_plonk_create(const uint8_t* zkey, size_t zkey_len, int device, g16_plonk** out);
+int g16_plonk_prove(g16_plonk* p, const uint8_t* wtns, size_t wtns_len, const uint8_t* blinding /* 9 * 32 or NULL */,
+                    g16_plonk_proof* out, uint8_t* pub);
+/* info: nVars (with the addition signals), nPublic, domainSize, nAdditions, nConstraints, addition dependency levels */
+int g16_plonk_get_info(const g16_plonk* p, uint32_t info[6]);
+void g16_plonk_destroy(g16_plonk* p);
+/* Test-only stand-in for `snarkjs plonk setup c.r1cs pot.ptau c.zkey` (/root/reference/Makefile:31) with a KNOWN tau
+ * (derived from seed): iden3 .r1cs v1 in, snarkjs-layout PLONK .zkey out (g16_free).  R1CS -> gates as plonk_setup.js
+ * does it; the selector / sigma transforms run on `device` (required), the N + 6 powers of tau through the fixed-base
+ * kernel.  with_lagrange = 0 writes an EMPTY section 13 (a prover that derives the public-input polynomial by NTT does
+ * not read it; snarkjs does). */
+int g16_plonk_setup(const uint8_t* r1cs, size_t r1cs_len, uint64_t seed, int device, int with_lagrange, uint8_t** zkey,
+                    size_t* zkey_len);
+
 #ifdef __cplusplus
 }
 #endif

@@ -37,6 +37,12 @@ class Proof(C.Structure):
     _fields_ = [("a", C.c_uint8 * 64), ("b", C.c_uint8 * 128), ("c", C.c_uint8 * 64)]
 
 
+class PlonkProof(C.Structure):
+    _fields_ = ([(k, C.c_uint8 * 64) for k in ("A", "B", "C", "Z", "T1", "T2", "T3")] +
+                [(k, C.c_uint8 * 32) for k in ("eval_a", "eval_b", "eval_c", "eval_s1", "eval_s2", "eval_zw", "eval_r")] +
+                [("Wxi", C.c_uint8 * 64), ("Wxiw", C.c_uint8 * 64)])
+
+
 class Info(C.Structure):
     _fields_ = [("n_vars", C.c_uint32), ("n_public", C.c_uint32), ("domain_size", C.c_uint32),
                 ("n_coefs", C.c_uint32), ("n_a", C.c_uint32), ("n_b1", C.c_uint32),
@@ -59,7 +65,8 @@ EXPORTS = ["g16_create", "g16_prove", "g16_prove_batch", "g16_stage_witness", "g
            "g16_f29_op", "g16_x29_op", "g16_qap_eval", "g16_shard_begin", "g16_shard_end",
            "g16_multi_create", "g16_multi_prove", "g16_multi_get_info", "g16_multi_destroy",
            "g16_nzcp_gadget", "g16_nzcp_circuit_setup", "g16_setup_device",
-           "g16_verifier_create", "g16_verify_batch", "g16_verifier_timings", "g16_verifier_destroy", "g16_pairing_op"]
+           "g16_verifier_create", "g16_verify_batch", "g16_verifier_timings", "g16_verifier_destroy", "g16_pairing_op",
+           "g16_plonk_create", "g16_plonk_prove", "g16_plonk_get_info", "g16_plonk_destroy", "g16_plonk_setup"]
 
 
 def load():
@@ -118,6 +125,12 @@ def load():
     lib.g16_verifier_destroy.argtypes = [vp]
     lib.g16_verifier_destroy.restype = None
     lib.g16_pairing_op.argtypes = [C.c_int, C.c_char_p, C.c_uint32, C.c_char_p]
+    lib.g16_plonk_create.argtypes = [C.c_char_p, sz, C.c_int, C.POINTER(vp)]
+    lib.g16_plonk_prove.argtypes = [vp, C.c_char_p, sz, C.c_char_p, C.POINTER(PlonkProof), C.c_char_p]
+    lib.g16_plonk_get_info.argtypes = [vp, C.POINTER(C.c_uint32)]
+    lib.g16_plonk_destroy.argtypes = [vp]
+    lib.g16_plonk_destroy.restype = None
+    lib.g16_plonk_setup.argtypes = [C.c_char_p, sz, C.c_uint64, C.c_int, C.c_int, C.POINTER(vp), C.POINTER(sz)]
     lib.g16_r1cs_setup.argtypes = [C.c_char_p, sz, C.c_uint64, C.c_int, C.POINTER(vp), C.POINTER(sz), C.POINTER(vp), C.POINTER(sz)]
     lib.g16_sha256_chain_setup.argtypes = [C.c_uint32, C.c_char_p, C.c_uint64, C.c_int] + [C.c_void_p] * 8
     lib.g16_sha256_message_setup.argtypes = [C.c_char_p, C.c_uint32, C.c_uint64, C.c_int] + [C.c_void_p] * 8
@@ -580,6 +593,66 @@ class Verifier:
             self._h = C.c_void_p()
 
     __del__ = close
+
+
+_PLONK_G1 = ("A", "B", "C", "Z", "T1", "T2", "T3")
+_PLONK_EV = ("eval_a", "eval_b", "eval_c", "eval_s1", "eval_s2", "eval_zw", "eval_r")
+
+
+class PlonkProver:
+    """Resident PLONK proving key on one GPU: snarkjs `plonk.prove(zkey, wtns)` -> (proof, publicSignals)."""
+
+    def __init__(self, zkey, device=0):
+        if isinstance(zkey, (str, os.PathLike)):
+            with open(zkey, "rb") as f:
+                zkey = f.read()
+        self._h = C.c_void_p()
+        _check(load().g16_plonk_create(zkey, len(zkey), device, C.byref(self._h)))
+        info = (C.c_uint32 * 6)()
+        _check(load().g16_plonk_get_info(self._h, info))
+        self.n_vars, self.n_public, self.domain_size, self.n_additions, self.n_constraints, self.levels = list(info)
+
+    def prove_raw(self, wtns, blinding=None):
+        pr = PlonkProof()
+        pub = C.create_string_buffer(max(1, self.n_public * 32))
+        _check(load().g16_plonk_prove(self._h, wtns, len(wtns), blinding, C.byref(pr), pub))
+        return pr, pub.raw[:self.n_public * 32]
+
+    def prove(self, wtns, blinding=None):
+        """blinding: None, or the nine scalars b1..b9 as ints (reproducible proof)."""
+        if blinding is not None and not isinstance(blinding, (bytes, bytearray)):
+            blinding = b"".join(int(x).to_bytes(32, "little") for x in blinding)
+        pr, pub = self.prove_raw(wtns, blinding)
+        return plonk_proof_to_obj(pr), [_dec(pub[i * 32:(i + 1) * 32]) for i in range(self.n_public)]
+
+    def close(self):
+        if getattr(self, "_h", None) and self._h.value:
+            load().g16_plonk_destroy(self._h)
+            self._h = C.c_void_p()
+
+    __del__ = close
+
+
+def plonk_setup(r1cs, seed, device=0, with_lagrange=True):
+    """Test-only PLONK setup with a known tau: .r1cs bytes -> snarkjs-layout PLONK .zkey bytes."""
+    z, zl = C.c_void_p(), C.c_size_t()
+    _check(load().g16_plonk_setup(r1cs, len(r1cs), seed, device, 1 if with_lagrange else 0, C.byref(z), C.byref(zl)))
+    return _take(z, zl)
+
+
+def plonk_proof_to_obj(pr):
+    """g16_plonk_proof -> the object `snarkjs plonk prove` stringifies (its key order)."""
+    def g1(b):
+        b = bytes(b)
+        return ["0", "1", "0"] if b == bytes(64) else [_dec(b[:32]), _dec(b[32:]), "1"]
+    o = {}
+    for k in _PLONK_G1:
+        o[k] = g1(getattr(pr, k))
+    for k in _PLONK_EV:
+        o[k] = _dec(bytes(getattr(pr, k)))
+    o["Wxi"], o["Wxiw"] = g1(pr.Wxi), g1(pr.Wxiw)
+    o["protocol"], o["curve"] = "plonk", "bn128"
+    return o
 
 
 def pairing_op(pairs, device=0):

@@ -738,7 +738,7 @@ static int lane_create(MsmLaneWs& ln, const MsmGroup& g, int curve, uint32_t key
   ln.task_len = g.task_len;
   if (curve == 2 && !g.task_len_forced) {
     const uint64_t t = entries_eff / 131072;
-    ln.task_len = (uint32_t)(t < 8 ? 8 : (t > 32 ? 32 : t));
+    ln.task_len = (uint32_t)(t < 16 ? 16 : (t > 32 ? 32 : t));
   }
   ln.seg_len = msm_seg_len_cfg(curve == 2 ? 1 : (g.dense ? 2 : 0));
   if (g.salt_bits) {   // a segment must not straddle two weights of the salted top window
@@ -750,7 +750,8 @@ static int lane_create(MsmLaneWs& ln, const MsmGroup& g, int curve, uint32_t key
   // leaves ~1.5 M entries of an estimated 12.8 M after the zero / one / repeated-value classes, and 32-entry tasks
   // then fill a fifth of the persistent grid (r02 sweep: 4.40 -> 4.18 ms per proof at 16; the synthetic witness, with
   // its 32 % full-width scalars, wants 32: 7.9 against 9.4 ms).
-  ln.task_len_min = g.task_len_forced ? ln.task_len : 16u;   // (8 on the G2 lane: measured worse, r02 sweep)
+  ln.task_len_min = ln.task_len < 16u ? ln.task_len : 16u;   // (8 on the G2 lane: measured worse, r02 sweep)
+  if (g.task_len_forced) ln.task_len_min = ln.task_len;
   // every non-empty bucket has <= 1 short task + entries / task_len full ones
   ln.max_tasks = nbk + entries / ln.task_len_min + 64;
   G16_HIP(hipHostMalloc((void**)&ln.h_stat, 64));

@@ -1,0 +1,999 @@
+// PLONK prover on the device (second half: "PLONK prover (the only flow the Makefile actually
+// scripts, /root/reference/Makefile:30-33) -- different protocol, reuse Fr NTT + G1 MSM kernels").
+//
+// Replaces `snarkjs plonk prove` ([EXT] snarkjs 0.4.12 plonk_prove.js, pin /root/reference/yarn.lock:987-1001) for a
+// PLONK .zkey as `snarkjs plonk setup` writes it (protocol id 2; sections: header, additions, A/B/C signal maps,
+// Qm Ql Qr Qo Qc, sigma 1-3, Lagrange polynomials, powers of tau; a polynomial = N coefficients + 4N evaluations).
+// Same five rounds, same Keccak-256 transcript, same blinding convention (b1..b9), so that with the same blinding
+// scalars the proof is the proof snarkjs computes; restated in oracle/plonk.py, which this file must match bit for bit.
+//
+// Device schedule (everything below on the canonical 8x32 Montgomery Fr of fp.cuh; transforms through ntt.hip's lazy
+// 9x29 format; commitments through the MSM group machinery with the powers of tau as a dense, window-precomputed
+// base section):
+//   witness   additions by dependency level (the setup's queue-order reduction makes a balanced tree: <= ~10 levels),
+//             A/B/C = w[map]
+//   round 1   3 x (iNTT N, blinding tweak, NTT 4N), 3 commitments
+//   round 2   grand product: per-lane chunks (batched inversion of the denominators, local prefix products), carries
+//             on the host, Z; iNTT N, NTT 4N, commitment
+//   round 3   one elementwise kernel over the 4N domain (gate, permutation and L1 terms with the blinding parts tracked
+//             apart: T and Tz), 2 iNTT 4N, division by Z_H as a stride-N recurrence, 3 commitments
+//   round 4   evaluations at xi by chunked Horner (device) + carry combination (host), linearisation polynomial r
+//   round 5   opening polynomials by chunked synthetic division, 2 commitments
+// The public-input polynomial comes from an iNTT/NTT of the public signals, not from the zkey's Lagrange section
+// (which is not read: 513 public signals at N = 2^22 make it 344 GB).
+#include <fcntl.h>
+#include <hip/hip_runtime.h>
+#include <unistd.h>
+
+#include <algorithm>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "internal.h"
+
+namespace g16 {
+namespace {
+
+using FrM = Fr;   // Montgomery residue
+constexpr uint32_t kChunk = 64;     // grand-product chunk per lane
+constexpr uint32_t kHorner = 256;   // Horner / synthetic-division chunk per lane
+
+// ------------------------------------------------------------------ host field helpers (fp.cuh host build)
+FrM h_from_u64(uint64_t v) {
+  Fr a = fp_zero<FrParams>();
+  a.v[0] = (uint32_t)v;
+  a.v[1] = (uint32_t)(v >> 32);
+  return fp_to_mont(a);
+}
+FrM h_root(int L) {
+  Fr w = {G16_FR_W28};
+  for (int i = 28; i > L; i--) w = fp_sqr(w);
+  return w;
+}
+FrM h_pow(FrM a, uint64_t e) { return fp_pow_u64(a, e); }
+bool h_lt_r(const uint32_t v[8]) {
+  static const uint32_t kR[8] = G16_FR_P;
+  for (int l = 7; l >= 0; l--)
+    if (v[l] != kR[l]) return v[l] < kR[l];
+  return false;
+}
+
+// ------------------------------------------------------------------ Keccak-256 (original 0x01 padding)
+void keccak_f(uint64_t s[25]) {
+  static const uint64_t RC[24] = {
+      0x0000000000000001ull, 0x0000000000008082ull, 0x800000000000808Aull, 0x8000000080008000ull, 0x000000000000808Bull,
+      0x0000000080000001ull, 0x8000000080008081ull, 0x8000000000008009ull, 0x000000000000008Aull, 0x0000000000000088ull,
+      0x0000000080008009ull, 0x000000008000000Aull, 0x000000008000808Bull, 0x800000000000008Bull, 0x8000000000008089ull,
+      0x8000000000008003ull, 0x8000000000008002ull, 0x8000000000000080ull, 0x000000000000800Aull, 0x800000008000000Aull,
+      0x8000000080008081ull, 0x8000000000008080ull, 0x0000000080000001ull, 0x8000000080008008ull};
+  static const int ROT[25] = {0, 1, 62, 28, 27, 36, 44, 6, 55, 20, 3, 10, 43, 25, 39, 41, 45, 15, 21, 8, 18, 2, 61, 56, 14};
+  auto rol = [](uint64_t x, int n) { return n ? (x << n) | (x >> (64 - n)) : x; };
+  for (int r = 0; r < 24; r++) {
+    uint64_t c[5], d[5], b[25];
+    for (int x = 0; x < 5; x++) c[x] = s[x] ^ s[x + 5] ^ s[x + 10] ^ s[x + 15] ^ s[x + 20];
+    for (int x = 0; x < 5; x++) d[x] = c[(x + 4) % 5] ^ rol(c[(x + 1) % 5], 1);
+    for (int i = 0; i < 25; i++) s[i] ^= d[i % 5];
+    for (int x = 0; x < 5; x++)
+      for (int y = 0; y < 5; y++) b[y + 5 * ((2 * x + 3 * y) % 5)] = rol(s[x + 5 * y], ROT[x + 5 * y]);
+    for (int x = 0; x < 5; x++)
+      for (int y = 0; y < 5; y++) s[x + 5 * y] = b[x + 5 * y] ^ ((~b[(x + 1) % 5 + 5 * y]) & b[(x + 2) % 5 + 5 * y]);
+    s[0] ^= RC[r];
+  }
+}
+void keccak256(const uint8_t* data, size_t len, uint8_t out[32]) {
+  const size_t rate = 136;
+  std::vector<uint8_t> m(data, data + len);
+  m.push_back(0x01);
+  while (m.size() % rate) m.push_back(0);
+  m.back() |= 0x80;
+  uint64_t s[25] = {0};
+  for (size_t off = 0; off < m.size(); off += rate) {
+    for (size_t i = 0; i < rate / 8; i++) {
+      uint64_t v = 0;
+      for (int k = 7; k >= 0; k--) v = (v << 8) | m[off + 8 * i + k];
+      s[i] ^= v;
+    }
+    keccak_f(s);
+  }
+  for (int i = 0; i < 4; i++)
+    for (int k = 0; k < 8; k++) out[8 * i + k] = (uint8_t)(s[i] >> (8 * k));
+}
+// hashToFr: the digest as a big-endian integer, reduced modulo r -> Montgomery
+FrM hash_to_fr(const std::vector<uint8_t>& t) {
+  uint8_t h[32];
+  keccak256(t.data(), t.size(), h);
+  Fr x;
+  for (int l = 0; l < 8; l++) {
+    uint32_t w = 0;
+    for (int k = 0; k < 4; k++) w = (w << 8) | h[32 - 4 * (l + 1) + k];
+    x.v[l] = w;
+  }
+  static const uint32_t kR[8] = G16_FR_P;
+  while (!h_lt_r(x.v)) {   // 2^256 / r < 6: a few subtractions
+    int64_t br = 0;
+    for (int i = 0; i < 8; i++) {
+      br += (int64_t)x.v[i] - (int64_t)kR[i];
+      x.v[i] = (uint32_t)br;
+      br >>= 32;
+    }
+  }
+  return fp_to_mont(x);
+}
+void put_be(std::vector<uint8_t>& t, const uint32_t v[8]) {   // 32-byte big-endian image of a standard-form integer
+  for (int l = 7; l >= 0; l--)
+    for (int k = 3; k >= 0; k--) t.push_back((uint8_t)(v[l] >> (8 * k)));
+}
+void put_fr_be(std::vector<uint8_t>& t, const FrM& x) {
+  const Fr s = fp_from_mont(x);
+  put_be(t, s.v);
+}
+void put_g1_be(std::vector<uint8_t>& t, const G1Affine& p) {   // Montgomery affine -> G1.toRprUncompressed
+  const Fq x = fp_from_mont(p.x), y = fp_from_mont(p.y);
+  put_be(t, x.v);
+  put_be(t, y.v);
+}
+
+// ------------------------------------------------------------------ device kernels
+__global__ __launch_bounds__(256) void k_to_mont(const Fr* __restrict__ in, FrM* __restrict__ out, uint32_t n, uint32_t zero_first) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  out[i] = (zero_first && i == 0) ? fp_zero<FrParams>() : fp_to_mont(in[i]);
+}
+// Montgomery -> standard form, zero padded to n_out (MSM scalars)
+__global__ __launch_bounds__(256) void k_from_mont_pad(const FrM* __restrict__ in, uint32_t n_in, Fr* __restrict__ out, uint32_t n_out) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_out) return;
+  out[i] = i < n_in ? fp_from_mont(in[i]) : fp_zero<FrParams>();
+}
+__global__ __launch_bounds__(256) void k_additions(const uint32_t* __restrict__ order, uint32_t lo, uint32_t hi,
+                                                   const uint32_t* __restrict__ s1, const uint32_t* __restrict__ s2,
+                                                   const FrM* __restrict__ f1, const FrM* __restrict__ f2,
+                                                   FrM* __restrict__ w, uint32_t base) {
+  const uint32_t t = lo + blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= hi) return;
+  const uint32_t k = order[t];
+  w[base + k] = fp_add(fp_mul(f1[k], w[s1[k]]), fp_mul(f2[k], w[s2[k]]));
+}
+__global__ __launch_bounds__(256) void k_gather(const FrM* __restrict__ w, const uint32_t* __restrict__ map, FrM* __restrict__ out, uint32_t n) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  out[i] = w[map[i]];
+}
+// pol = coefs (n) with the blinding polynomial (pz[0] + pz[1] X + ...)(X^n - 1) added: pol has n + npz entries
+struct Pz { FrM v[3]; uint32_t n; };
+__global__ void k_blind(const FrM* __restrict__ coefs, uint32_t n, Pz pz, FrM* __restrict__ pol) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n + pz.n) return;
+  FrM x = i < n ? coefs[i] : fp_zero<FrParams>();
+  if (i < pz.n) x = fp_sub(x, pz.v[i]);
+  if (i >= n) x = fp_add(x, pz.v[i - n]);
+  pol[i] = x;
+}
+__global__ __launch_bounds__(256) void k_pad4(const FrM* __restrict__ coefs, uint32_t n, FrM* __restrict__ out) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= 4 * n) return;
+  out[i] = i < n ? coefs[i] : fp_zero<FrParams>();
+}
+// out[i] = w^i, i < n (each lane: one power by square-and-multiply, then kChunk successive products)
+__global__ __launch_bounds__(256) void k_powers(FrM w, uint32_t n, FrM* __restrict__ out) {
+  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t lo = t * kChunk;
+  if (lo >= n) return;
+  FrM x = fp_pow_u64(w, lo);
+  const uint32_t hi = lo + kChunk < n ? lo + kChunk : n;
+  for (uint32_t i = lo; i < hi; i++) {
+    out[i] = x;
+    x = fp_mul(x, w);
+  }
+}
+
+struct R2Args { FrM beta, gamma, k1, k2, w1; };
+// round 2, per chunk: ratio[i] = num_i / den_i (denominators inverted in one batch per lane), lp[i] = inclusive local
+// prefix product of the ratios, totals[chunk] = the chunk's product
+__global__ __launch_bounds__(256) void k_z_local(const FrM* __restrict__ A, const FrM* __restrict__ B, const FrM* __restrict__ C,
+                                                 const FrM* __restrict__ S1e, const FrM* __restrict__ S2e, const FrM* __restrict__ S3e,
+                                                 R2Args a, uint32_t n, FrM* __restrict__ num, FrM* __restrict__ den,
+                                                 FrM* __restrict__ pre, FrM* __restrict__ lp, FrM* __restrict__ totals) {
+  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t lo = t * kChunk;
+  if (lo >= n) return;
+  const uint32_t hi = lo + kChunk < n ? lo + kChunk : n;
+  FrM w = fp_pow_u64(a.w1, lo);
+  FrM run = fp_one<FrParams>();
+  for (uint32_t i = lo; i < hi; i++) {
+    const FrM bw = fp_mul(a.beta, w);
+    const FrM n1 = fp_add(fp_add(A[i], bw), a.gamma);
+    const FrM n2 = fp_add(fp_add(B[i], fp_mul(a.k1, bw)), a.gamma);
+    const FrM n3 = fp_add(fp_add(C[i], fp_mul(a.k2, bw)), a.gamma);
+    num[i] = fp_mul(fp_mul(n1, n2), n3);
+    const FrM d1 = fp_add(fp_add(A[i], fp_mul(a.beta, S1e[4 * (size_t)i])), a.gamma);
+    const FrM d2 = fp_add(fp_add(B[i], fp_mul(a.beta, S2e[4 * (size_t)i])), a.gamma);
+    const FrM d3 = fp_add(fp_add(C[i], fp_mul(a.beta, S3e[4 * (size_t)i])), a.gamma);
+    const FrM d = fp_mul(fp_mul(d1, d2), d3);
+    den[i] = d;
+    pre[i] = run;
+    run = fp_mul(run, d);
+    w = fp_mul(w, a.w1);
+  }
+  FrM inv = fp_inv(run);
+  for (uint32_t i = hi; i-- > lo;) {
+    const FrM di = fp_mul(inv, pre[i]);
+    inv = fp_mul(inv, den[i]);
+    num[i] = fp_mul(num[i], di);   // the ratio
+  }
+  run = fp_one<FrParams>();
+  for (uint32_t i = lo; i < hi; i++) {
+    run = fp_mul(run, num[i]);
+    lp[i] = run;
+  }
+  totals[t] = run;
+}
+// Z[0] = 1, Z[i + 1] = carry[chunk(i)] * lp[i]
+__global__ __launch_bounds__(256) void k_z_apply(const FrM* __restrict__ lp, const FrM* __restrict__ carry, uint32_t n, FrM* __restrict__ Z) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  if (i == 0) Z[0] = fp_one<FrParams>();
+  if (i + 1 < n) Z[i + 1] = fp_mul(carry[i / kChunk], lp[i]);
+}
+
+struct R3Args {
+  FrM beta, gamma, alpha, alpha2, k1, k2, w1;
+  FrM b[10];
+  FrM Z1[4], Z2[4], Z3[4];
+};
+struct R3Ptrs {
+  const FrM *A4, *B4, *C4, *Z4, *qm, *ql, *qr, *qo, *qc, *s1, *s2, *s3, *pi4, *l1, *om4;
+};
+// (c0 + c1 t)(x + xp t) style accumulation of the blinded factors: the coefficients of t^k of prod (x_k + xp_k t)
+__device__ __forceinline__ void poly_mul_lin(FrM* c, int deg, const FrM& x, const FrM& xp) {
+  // c has deg + 1 coefficients; result deg + 2
+  FrM carry = fp_zero<FrParams>();
+  for (int k = 0; k <= deg; k++) {
+    const FrM lo = fp_mul(c[k], x);
+    const FrM hi = fp_mul(c[k], xp);
+    c[k] = fp_add(lo, carry);
+    carry = hi;
+  }
+  c[deg + 1] = carry;
+}
+__device__ __forceinline__ void mul4z(const FrM& x, const FrM& y, const FrM& u, const FrM& v, const FrM& xp, const FrM& yp,
+                                      const FrM& up, const FrM& vp, uint32_t p, const R3Args& a, FrM& r, FrM& rz) {
+  FrM c[5];
+  c[0] = x;
+  c[1] = xp;
+  poly_mul_lin(c, 1, y, yp);
+  poly_mul_lin(c, 2, u, up);
+  poly_mul_lin(c, 3, v, vp);
+  r = c[0];
+  rz = c[1];
+  if (p) rz = fp_add(rz, fp_add(fp_mul(a.Z1[p], c[2]), fp_add(fp_mul(a.Z2[p], c[3]), fp_mul(a.Z3[p], c[4]))));
+}
+__global__ __launch_bounds__(256) void k_round3(R3Ptrs q, R3Args a, uint32_t n4, FrM* __restrict__ T, FrM* __restrict__ Tz) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n4) return;
+  const uint32_t p = i & 3u;
+  const FrM w = q.om4[i];
+  const FrM A = q.A4[i], B = q.B4[i], C = q.C4[i], Z = q.Z4[i], ZW = q.Z4[(i + 4) % n4];
+  const FrM ap = fp_add(a.b[2], fp_mul(a.b[1], w));
+  const FrM bp = fp_add(a.b[4], fp_mul(a.b[3], w));
+  const FrM cp = fp_add(a.b[6], fp_mul(a.b[5], w));
+  const FrM w2 = fp_sqr(w);
+  const FrM zp = fp_add(fp_add(fp_mul(a.b[7], w2), fp_mul(a.b[8], w)), a.b[9]);
+  const FrM ww = fp_mul(w, a.w1);
+  const FrM zwp = fp_add(fp_add(fp_mul(a.b[7], fp_sqr(ww)), fp_mul(a.b[8], ww)), a.b[9]);
+  // gate
+  const FrM qm = q.qm[i], ql = q.ql[i], qr = q.qr[i], qo = q.qo[i];
+  FrM e1 = fp_mul(fp_mul(A, B), qm);
+  FrM e1z = fp_add(fp_mul(A, bp), fp_mul(ap, B));
+  if (p) e1z = fp_add(e1z, fp_mul(a.Z1[p], fp_mul(ap, bp)));
+  e1z = fp_mul(e1z, qm);
+  e1 = fp_add(e1, fp_add(fp_add(fp_mul(A, ql), fp_mul(B, qr)), fp_add(fp_mul(C, qo), fp_add(q.pi4[i], q.qc[i]))));
+  e1z = fp_add(e1z, fp_add(fp_add(fp_mul(ap, ql), fp_mul(bp, qr)), fp_mul(cp, qo)));
+  // permutation
+  const FrM bw = fp_mul(a.beta, w);
+  FrM e2, e2z, e3, e3z;
+  mul4z(fp_add(fp_add(A, bw), a.gamma), fp_add(fp_add(B, fp_mul(bw, a.k1)), a.gamma), fp_add(fp_add(C, fp_mul(bw, a.k2)), a.gamma), Z,
+        ap, bp, cp, zp, p, a, e2, e2z);
+  mul4z(fp_add(fp_add(A, fp_mul(a.beta, q.s1[i])), a.gamma), fp_add(fp_add(B, fp_mul(a.beta, q.s2[i])), a.gamma),
+        fp_add(fp_add(C, fp_mul(a.beta, q.s3[i])), a.gamma), ZW, ap, bp, cp, zwp, p, a, e3, e3z);
+  const FrM l1 = q.l1[i];
+  const FrM e4 = fp_mul(fp_mul(fp_sub(Z, fp_one<FrParams>()), l1), a.alpha2);
+  const FrM e4z = fp_mul(fp_mul(zp, l1), a.alpha2);
+  T[i] = fp_add(fp_add(e1, fp_mul(a.alpha, fp_sub(e2, e3))), e4);
+  Tz[i] = fp_add(fp_add(e1z, fp_mul(a.alpha, fp_sub(e2z, e3z))), e4z);
+}
+// t = numerator / (X^n - 1) on 4n coefficients, in place: q_j = -p_j, q_{j+kn} = q_{j+(k-1)n} - p_{j+kn}; bad[0] is set
+// when a coefficient above 3n - 4 of the quotient is not zero.  Then t += tz below 3n + 6 (bad[1]: tz not zero above).
+__global__ __launch_bounds__(256) void k_div_zh(FrM* __restrict__ t, const FrM* __restrict__ tz, uint32_t n, uint32_t* __restrict__ bad) {
+  const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= n) return;
+  FrM qv = fp_neg(t[j]);
+  t[j] = fp_add(qv, tz[j]);
+  for (uint32_t k = 1; k < 4; k++) {
+    const uint32_t i = j + k * n;
+    qv = fp_sub(qv, t[i]);
+    if (i > 3 * n - 4 && !fp_is_zero(qv)) atomicOr(&bad[0], 1u);
+    if (i > 3 * n + 5) {
+      if (!fp_is_zero(tz[i])) atomicOr(&bad[1], 1u);
+      t[i] = qv;
+    } else {
+      t[i] = fp_add(qv, tz[i]);
+    }
+  }
+}
+// H[c] = sum_{j < len_c} P[c kHorner + j] x^j
+__global__ __launch_bounds__(256) void k_horner(const FrM* __restrict__ P, uint32_t n, FrM x, FrM* __restrict__ H) {
+  const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t lo = c * kHorner;
+  if (lo >= n) return;
+  const uint32_t hi = lo + kHorner < n ? lo + kHorner : n;
+  FrM r = fp_zero<FrParams>();
+  for (uint32_t i = hi; i-- > lo;) r = fp_add(fp_mul(r, x), P[i]);
+  H[c] = r;
+}
+// synthetic division by (X - d): res[i] = P[i+1] + d res[i+1]; E[c + 1] = res at the top index of chunk c
+__global__ __launch_bounds__(256) void k_divpol(const FrM* __restrict__ P, uint32_t n, FrM d, const FrM* __restrict__ E, FrM* __restrict__ res) {
+  const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t lo = c * kHorner;
+  if (lo >= n) return;
+  const uint32_t hi = lo + kHorner < n ? lo + kHorner : n;
+  FrM r = E[c + 1];
+  for (uint32_t i = hi; i-- > lo;) {
+    res[i] = r;
+    r = fp_add(P[i], fp_mul(d, r));
+  }
+}
+struct R4Args { FrM coefz, coef_ab, ea, eb, ec, coefs3; };
+// pol_r[i] = coefz z[i] (+ coef_ab qm + ea ql + eb qr + ec qo + qc - coefs3 s3 for i < n), i < n + 3
+__global__ __launch_bounds__(256) void k_pol_r(const FrM* __restrict__ z, const FrM* __restrict__ qm, const FrM* __restrict__ ql,
+                                               const FrM* __restrict__ qr, const FrM* __restrict__ qo, const FrM* __restrict__ qc,
+                                               const FrM* __restrict__ s3, R4Args a, uint32_t n, FrM* __restrict__ r) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n + 3) return;
+  FrM v = fp_mul(a.coefz, z[i]);
+  if (i < n) {
+    v = fp_add(v, fp_mul(a.coef_ab, qm[i]));
+    v = fp_add(v, fp_mul(a.ea, ql[i]));
+    v = fp_add(v, fp_mul(a.eb, qr[i]));
+    v = fp_add(v, fp_mul(a.ec, qo[i]));
+    v = fp_add(v, qc[i]);
+    v = fp_sub(v, fp_mul(a.coefs3, s3[i]));
+  }
+  r[i] = v;
+}
+struct R5Args { FrM v[7], xim, xi2m, sub0; };
+__global__ __launch_bounds__(256) void k_pol_wxi(const FrM* __restrict__ t, const FrM* __restrict__ r, const FrM* __restrict__ pa,
+                                                 const FrM* __restrict__ pb, const FrM* __restrict__ pc, const FrM* __restrict__ s1,
+                                                 const FrM* __restrict__ s2, R5Args a, uint32_t n, FrM* __restrict__ out) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n + 6) return;
+  FrM w = fp_mul(a.xi2m, t[2 * (size_t)n + i]);
+  if (i < n + 3) w = fp_add(w, fp_mul(a.v[1], r[i]));
+  if (i < n + 2) {
+    w = fp_add(w, fp_mul(a.v[2], pa[i]));
+    w = fp_add(w, fp_mul(a.v[3], pb[i]));
+    w = fp_add(w, fp_mul(a.v[4], pc[i]));
+  }
+  if (i < n) {
+    w = fp_add(w, t[i]);
+    w = fp_add(w, fp_mul(a.xim, t[(size_t)n + i]));
+    w = fp_add(w, fp_mul(a.v[5], s1[i]));
+    w = fp_add(w, fp_mul(a.v[6], s2[i]));
+  }
+  if (i == 0) w = fp_sub(w, a.sub0);
+  out[i] = w;
+}
+__global__ void k_sub0(FrM* __restrict__ p, FrM v) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) p[0] = fp_sub(p[0], v);
+}
+// -pub[j] at j < n_public, 0 elsewhere (the N evaluations of the public-input polynomial)
+__global__ __launch_bounds__(256) void k_pi_evals(const FrM* __restrict__ A, uint32_t n_public, uint32_t n, FrM* __restrict__ out) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  out[i] = i < n_public ? fp_neg(A[i]) : fp_zero<FrParams>();
+}
+
+inline unsigned nblk(size_t n, unsigned per = 256) { return (unsigned)((n + per - 1) / per); }
+
+}  // namespace
+}  // namespace g16
+
+using namespace g16;
+
+struct g16_plonk {
+  int device = 0;
+  uint32_t N = 0, L = 0, nVars = 0, nPublic = 0, nAdd = 0, nCons = 0, nBase = 0;
+  FrM k1, k2, w1;
+  hipStream_t st = nullptr;
+  NttTables ntt_n, ntt_4n;
+  FrM* d_ext[8] = {};     // Qm Ql Qr Qo Qc S1 S2 S3, 4N evaluations
+  FrM* d_pol[8] = {};     // ... N coefficients
+  uint32_t* d_map[3] = {};
+  uint32_t *d_add_s1 = nullptr, *d_add_s2 = nullptr, *d_add_order = nullptr;
+  FrM *d_add_f1 = nullptr, *d_add_f2 = nullptr;
+  std::vector<uint32_t> level_start;
+  FrM *d_om4 = nullptr, *d_l1 = nullptr;
+  MsmGroup srs;
+  MsmWorkspace* ws = nullptr;
+  // per-proof scratch
+  Fr* d_wraw = nullptr;                 // witness as uploaded (standard form)
+  FrM* d_w = nullptr;                   // extended witness, Montgomery
+  FrM *d_A = nullptr, *d_B = nullptr, *d_C = nullptr, *d_Z = nullptr;   // N evaluations
+  FrM *d_pa = nullptr, *d_pb = nullptr, *d_pc = nullptr, *d_pz = nullptr;   // blinded coefficient forms (N + 3)
+  FrM *d_A4 = nullptr, *d_B4 = nullptr, *d_C4 = nullptr, *d_Z4 = nullptr, *d_T = nullptr, *d_Tz = nullptr, *d_pi4 = nullptr;
+  FrM *d_tmpN = nullptr, *d_tmpN2 = nullptr, *d_tmpN3 = nullptr, *d_tmpN4 = nullptr;   // N-sized scratch
+  FrM *d_r = nullptr, *d_wxi = nullptr, *d_q = nullptr;
+  FrM *d_tot = nullptr;                 // chunk totals / Horner partials
+  F29* d_lazy = nullptr;                // 4N lazy elements: the transforms' working vector
+  Fr* d_scal = nullptr;                 // N + 6 standard-form MSM scalars
+  uint32_t* d_bad = nullptr;
+  std::vector<FrM> h_tot;
+  float last_ms[6] = {};
+  std::mutex mu;
+  ~g16_plonk() {
+    (void)hipSetDevice(device);
+    for (auto p : d_ext) if (p) (void)hipFree(p);
+    for (auto p : d_pol) if (p) (void)hipFree(p);
+    for (auto p : d_map) if (p) (void)hipFree(p);
+    void* v[] = {d_add_s1, d_add_s2, d_add_order, d_add_f1, d_add_f2, d_om4, d_l1, d_wraw, d_w, d_A, d_B, d_C, d_Z, d_pa, d_pb, d_pc,
+                 d_pz, d_A4, d_B4, d_C4, d_Z4, d_T, d_Tz, d_pi4, d_tmpN, d_tmpN2, d_tmpN3, d_tmpN4, d_r, d_wxi, d_q, d_tot, d_lazy,
+                 d_scal, d_bad};
+    for (void* p : v) if (p) (void)hipFree(p);
+    if (ws) msm_workspace_destroy(ws);
+    msm_group_destroy(srs);
+    ntt_tables_destroy(ntt_n);
+    ntt_tables_destroy(ntt_4n);
+    if (st) (void)hipStreamDestroy(st);
+  }
+};
+
+namespace {
+
+struct Sec { const uint8_t* p = nullptr; uint64_t size = 0; };
+int find_sections(const uint8_t* buf, size_t len, const char* magic, Sec out[16], const char* name) {
+  if (len < 12 || memcmp(buf, magic, 4) != 0) { set_error(std::string(name) + ": Invalid File format"); return G16_E_FORMAT; }
+  uint32_t version, nsec;
+  memcpy(&version, buf + 4, 4);
+  memcpy(&nsec, buf + 8, 4);
+  if (version > 2) { set_error("Version not supported"); return G16_E_FORMAT; }
+  size_t pos = 12;
+  for (uint32_t i = 0; i < nsec; i++) {
+    if (pos + 12 > len) { set_error(std::string(name) + ": Invalid File format"); return G16_E_FORMAT; }
+    uint32_t id;
+    uint64_t size;
+    memcpy(&id, buf + pos, 4);
+    memcpy(&size, buf + pos + 4, 8);
+    pos += 12;
+    if (size > len - pos) { set_error(std::string(name) + ": Invalid File format"); return G16_E_FORMAT; }
+    if (id < 16 && !out[id].p) { out[id].p = buf + pos; out[id].size = size; }
+    pos += size;
+  }
+  return G16_OK;
+}
+
+// transforms of Montgomery vectors through the lazy working vector (natural order in and out)
+int do_ifft(const NttTables& t, const FrM* in, FrM* out, F29* lazy, hipStream_t st) {
+  int rc = ntt_import(t, in, lazy, false, st);
+  F29* v[1] = {lazy};
+  if (!rc) rc = ntt_dif_inverse(t, v, 1, st);
+  if (!rc) rc = ntt_export(t, lazy, out, true, true, st);
+  return rc;
+}
+int do_fft(const NttTables& t, const FrM* in, FrM* out, F29* lazy, hipStream_t st) {
+  int rc = ntt_import(t, in, lazy, true, st);
+  F29* v[1] = {lazy};
+  if (!rc) rc = ntt_dit_forward(t, v, 1, st);
+  if (!rc) rc = ntt_export(t, lazy, out, false, false, st);
+  return rc;
+}
+
+int plonk_create_impl(const uint8_t* zkey, size_t len, int device, g16_plonk* P) {
+  Sec s[16];
+  int rc = find_sections(zkey, len, "zkey", s, "zkey");
+  if (rc) return rc;
+  if (!s[1].p || s[1].size < 4) { set_error("zkey: Invalid File format"); return G16_E_FORMAT; }
+  uint32_t proto;
+  memcpy(&proto, s[1].p, 4);
+  if (proto != 2) { set_error("zkey file is not plonk"); return G16_E_FORMAT; }
+  const size_t hdr = 4 + 32 + 4 + 32 + 20 + 64 + 8 * 64 + 128;
+  if (!s[2].p || s[2].size < hdr) { set_error("zkey: Invalid File format"); return G16_E_FORMAT; }
+  {
+    static const uint32_t Qp[8] = G16_FQ_P, Rp[8] = G16_FR_P;
+    uint32_t n8q, n8r;
+    memcpy(&n8q, s[2].p, 4);
+    memcpy(&n8r, s[2].p + 36, 4);
+    if (n8q != 32 || n8r != 32 || memcmp(s[2].p + 4, Qp, 32) != 0 || memcmp(s[2].p + 40, Rp, 32) != 0) {
+      set_error("zkey: curve not supported (bn128 only)");
+      return G16_E_FORMAT;
+    }
+  }
+  const uint8_t* h = s[2].p + 72;
+  memcpy(&P->nVars, h, 4);
+  memcpy(&P->nPublic, h + 4, 4);
+  memcpy(&P->N, h + 8, 4);
+  memcpy(&P->nAdd, h + 12, 4);
+  memcpy(&P->nCons, h + 16, 4);
+  memcpy(P->k1.v, h + 20, 32);
+  memcpy(P->k2.v, h + 52, 32);
+  const uint32_t N = P->N;
+  if (N < 4 || (N & (N - 1)) || N > (1u << 24) || P->nCons > N || P->nAdd > P->nVars || P->nPublic >= P->nVars - P->nAdd) {
+    set_error("zkey: Invalid File format");
+    return G16_E_FORMAT;
+  }
+  while ((1u << P->L) < N) P->L++;
+  P->nBase = P->nVars - P->nAdd;
+  P->w1 = h_root((int)P->L);
+  const size_t polb = (size_t)N * 32 * 5;
+  if (!s[3].p || s[3].size != (uint64_t)P->nAdd * 72 || s[4].size != (uint64_t)P->nCons * 4 || s[5].size != s[4].size ||
+      s[6].size != s[4].size || s[12].size != 3 * polb || s[14].size != ((uint64_t)N + 6) * 64) {
+    set_error("zkey: Invalid File format");
+    return G16_E_FORMAT;
+  }
+  for (int k = 7; k <= 11; k++)
+    if (s[k].size != polb) { set_error("zkey: Invalid File format"); return G16_E_FORMAT; }
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { set_error("no HIP device: the PLONK prover has no CPU path"); return G16_E_NOGPU; }
+  if (device < 0 || device >= ndev) { set_error("bad device ordinal"); return G16_E_ARG; }
+  P->device = device;
+  G16_HIP(hipSetDevice(device));
+  G16_HIP(hipStreamCreate(&P->st));
+  hipStream_t st = P->st;
+  if ((rc = ntt_tables_create(P->ntt_n, (int)P->L, st))) return rc;
+  if ((rc = ntt_tables_create(P->ntt_4n, (int)P->L + 2, st))) return rc;
+  // polynomials: coefficients (N) then evaluations (4N)
+  for (int k = 0; k < 8; k++) {
+    const uint8_t* src = k < 5 ? s[7 + k].p : s[12].p + (size_t)(k - 5) * polb;
+    G16_HIP(hipMalloc(&P->d_pol[k], (size_t)N * 32));
+    G16_HIP(hipMalloc(&P->d_ext[k], (size_t)N * 128));
+    G16_HIP(hipMemcpyAsync(P->d_pol[k], src, (size_t)N * 32, hipMemcpyHostToDevice, st));
+    G16_HIP(hipMemcpyAsync(P->d_ext[k], src + (size_t)N * 32, (size_t)N * 128, hipMemcpyHostToDevice, st));
+  }
+  // maps, zero padded to N
+  for (int c = 0; c < 3; c++) {
+    G16_HIP(hipMalloc(&P->d_map[c], (size_t)N * 4));
+    G16_HIP(hipMemsetAsync(P->d_map[c], 0, (size_t)N * 4, st));
+    if (P->nCons) G16_HIP(hipMemcpyAsync(P->d_map[c], s[4 + c].p, (size_t)P->nCons * 4, hipMemcpyHostToDevice, st));
+    for (uint32_t i = 0; i < P->nCons; i++) {
+      uint32_t v;
+      memcpy(&v, s[4 + c].p + (size_t)i * 4, 4);
+      if (v >= P->nVars) { set_error("zkey: signal map out of range"); return G16_E_FORMAT; }
+    }
+  }
+  // additions: split into arrays, ordered by dependency level
+  {
+    const uint32_t na = P->nAdd;
+    std::vector<uint32_t> s1(na), s2(na), lvl(na), order(na);
+    std::vector<FrM> f1(na), f2(na);
+    uint32_t maxl = 0;
+    for (uint32_t k = 0; k < na; k++) {
+      const uint8_t* r = s[3].p + (size_t)k * 72;
+      memcpy(&s1[k], r, 4);
+      memcpy(&s2[k], r + 4, 4);
+      memcpy(f1[k].v, r + 8, 32);
+      memcpy(f2[k].v, r + 40, 32);
+      if (s1[k] >= P->nBase + k || s2[k] >= P->nBase + k) { set_error("zkey: addition refers to a later signal"); return G16_E_FORMAT; }
+      const uint32_t l1 = s1[k] >= P->nBase ? lvl[s1[k] - P->nBase] + 1 : 0, l2 = s2[k] >= P->nBase ? lvl[s2[k] - P->nBase] + 1 : 0;
+      lvl[k] = l1 > l2 ? l1 : l2;
+      if (lvl[k] > maxl) maxl = lvl[k];
+    }
+    std::vector<uint32_t> cnt(maxl + 2, 0);
+    for (uint32_t k = 0; k < na; k++) cnt[lvl[k] + 1]++;
+    for (uint32_t l = 0; l <= maxl; l++) cnt[l + 1] += cnt[l];
+    P->level_start.assign(cnt.begin(), cnt.end());
+    std::vector<uint32_t> cur(cnt.begin(), cnt.end() - 1);
+    for (uint32_t k = 0; k < na; k++) order[cur[lvl[k]]++] = k;
+    if (na) {
+      G16_HIP(hipMalloc(&P->d_add_s1, (size_t)na * 4));
+      G16_HIP(hipMalloc(&P->d_add_s2, (size_t)na * 4));
+      G16_HIP(hipMalloc(&P->d_add_order, (size_t)na * 4));
+      G16_HIP(hipMalloc(&P->d_add_f1, (size_t)na * 32));
+      G16_HIP(hipMalloc(&P->d_add_f2, (size_t)na * 32));
+      G16_HIP(hipMemcpy(P->d_add_s1, s1.data(), (size_t)na * 4, hipMemcpyHostToDevice));
+      G16_HIP(hipMemcpy(P->d_add_s2, s2.data(), (size_t)na * 4, hipMemcpyHostToDevice));
+      G16_HIP(hipMemcpy(P->d_add_order, order.data(), (size_t)na * 4, hipMemcpyHostToDevice));
+      G16_HIP(hipMemcpy(P->d_add_f1, f1.data(), (size_t)na * 32, hipMemcpyHostToDevice));
+      G16_HIP(hipMemcpy(P->d_add_f2, f2.data(), (size_t)na * 32, hipMemcpyHostToDevice));
+    }
+  }
+  // scratch
+  const size_t n4 = (size_t)N * 4;
+  FrM** four[] = {&P->d_A4, &P->d_B4, &P->d_C4, &P->d_Z4, &P->d_T, &P->d_Tz, &P->d_pi4, &P->d_om4, &P->d_l1};
+  for (FrM** p : four) G16_HIP(hipMalloc(p, n4 * 32));
+  FrM** one[] = {&P->d_A, &P->d_B, &P->d_C, &P->d_Z, &P->d_tmpN, &P->d_tmpN2, &P->d_tmpN3, &P->d_tmpN4};
+  for (FrM** p : one) G16_HIP(hipMalloc(p, (size_t)N * 32));
+  FrM** plus[] = {&P->d_pa, &P->d_pb, &P->d_pc, &P->d_pz, &P->d_r, &P->d_wxi, &P->d_q};
+  for (FrM** p : plus) G16_HIP(hipMalloc(p, ((size_t)N + 8) * 32));
+  G16_HIP(hipMalloc(&P->d_wraw, (size_t)P->nBase * 32));
+  G16_HIP(hipMalloc(&P->d_w, (size_t)P->nVars * 32));
+  G16_HIP(hipMalloc(&P->d_lazy, n4 * sizeof(F29)));
+  G16_HIP(hipMalloc(&P->d_scal, ((size_t)N + 8) * 32));
+  G16_HIP(hipMalloc(&P->d_tot, (n4 / kChunk + 8) * 32));
+  G16_HIP(hipMalloc(&P->d_bad, 64));
+  P->h_tot.resize(n4 / kChunk + 8);
+  // w_4N^i and the 4N evaluations of L1 = NTT(iNTT(e_0))
+  k_powers<<<nblk(nblk(n4, kChunk)), 256, 0, st>>>(h_root((int)P->L + 2), (uint32_t)n4, P->d_om4);
+  {
+    G16_HIP(hipMemsetAsync(P->d_tmpN, 0, (size_t)N * 32, st));
+    const FrM one_m = fp_one<FrParams>();
+    G16_HIP(hipMemcpyAsync(P->d_tmpN, &one_m, 32, hipMemcpyHostToDevice, st));
+    if ((rc = do_ifft(P->ntt_n, P->d_tmpN, P->d_tmpN2, P->d_lazy, st))) return rc;
+    k_pad4<<<nblk(n4), 256, 0, st>>>(P->d_tmpN2, N, P->d_T);
+    if ((rc = do_fft(P->ntt_4n, P->d_T, P->d_l1, P->d_lazy, st))) return rc;
+  }
+  G16_HIP(hipGetLastError());
+  G16_HIP(hipStreamSynchronize(st));
+  // powers of tau: one dense base section
+  MsmSectionIn sec;
+  sec.bases_host = s[14].p;
+  sec.n_total = N + 6;
+  MsmConfig cfg;
+  cfg.dense = true;
+  if ((rc = msm_group_create(P->srs, &sec, 1, cfg))) return rc;
+  if (P->srs.n != N + 6) { set_error("zkey: a power of tau is the point at infinity"); return G16_E_FORMAT; }
+  if ((rc = msm_workspace_create(&P->ws, P->srs))) return rc;
+  return G16_OK;
+}
+
+struct PlonkProofM {   // points affine Montgomery, evaluations Montgomery
+  G1Affine A, B, C, Z, T1, T2, T3, Wxi, Wxiw;
+  FrM ea, eb, ec, es1, es2, ezw, er;
+};
+
+// commitment of `len` Montgomery coefficients starting at d_coefs: sum coef_i [tau^i]
+int commit(g16_plonk* P, const FrM* d_coefs, uint32_t len, G1Affine* out) {
+  const uint32_t np = P->N + 6;
+  k_from_mont_pad<<<nblk(np), 256, 0, P->st>>>(d_coefs, len, P->d_scal, np);
+  G16_HIP(hipGetLastError());
+  int rc = msm_launch(P->srs, P->ws, P->d_scal, P->st, P->st);
+  if (rc) return rc;
+  MsmResult res;
+  if ((rc = msm_collect(P->srs, P->ws, &res))) return rc;
+  xyzz_to_affine(*out, res.g1[0]);
+  return G16_OK;
+}
+
+// sum_i P[i] x^i over n device coefficients: chunked Horner on the device, the chunk values combined on the host
+int eval_pol(g16_plonk* P, const FrM* d_pol, uint32_t n, const FrM& x, FrM* out) {
+  const uint32_t nc = (n + kHorner - 1) / kHorner;
+  k_horner<<<nblk(nc), 256, 0, P->st>>>(d_pol, n, x, P->d_tot);
+  G16_HIP(hipGetLastError());
+  G16_HIP(hipMemcpyAsync(P->h_tot.data(), P->d_tot, (size_t)nc * 32, hipMemcpyDeviceToHost, P->st));
+  G16_HIP(hipStreamSynchronize(P->st));
+  const FrM xc = h_pow(x, kHorner);
+  FrM r = fp_zero<FrParams>();
+  for (uint32_t c = nc; c-- > 0;) r = fp_add(fp_mul(r, xc), P->h_tot[c]);
+  *out = r;
+  return G16_OK;
+}
+
+// res = (P - P(d)) / (X - d) for a P with P(d) == 0 (n coefficients; res has n entries, the top one zero)
+int div_pol1(g16_plonk* P, const FrM* d_pol, uint32_t n, const FrM& d, FrM* d_res) {
+  const uint32_t nc = (n + kHorner - 1) / kHorner;
+  k_horner<<<nblk(nc), 256, 0, P->st>>>(d_pol, n, d, P->d_tot);
+  G16_HIP(hipGetLastError());
+  G16_HIP(hipMemcpyAsync(P->h_tot.data(), P->d_tot, (size_t)nc * 32, hipMemcpyDeviceToHost, P->st));
+  G16_HIP(hipStreamSynchronize(P->st));
+  // E[c] = sum_{j >= lo_c} P[j] d^(j - lo_c) = H[c] + d^len_c E[c + 1]; every chunk but the last is full
+  std::vector<FrM> E(nc + 1);
+  E[nc] = fp_zero<FrParams>();
+  const FrM dc = h_pow(d, kHorner);
+  for (uint32_t c = nc; c-- > 0;) {
+    const uint32_t lenc = c + 1 == nc ? n - c * kHorner : kHorner;
+    E[c] = fp_add(P->h_tot[c], fp_mul(lenc == kHorner ? dc : h_pow(d, lenc), E[c + 1]));
+  }
+  if (!fp_is_zero(E[0])) { set_error("Polinomial does not divide"); return G16_E_STATE; }
+  G16_HIP(hipMemcpyAsync(P->d_tot, E.data(), (size_t)(nc + 1) * 32, hipMemcpyHostToDevice, P->st));
+  k_divpol<<<nblk(nc), 256, 0, P->st>>>(d_pol, n, d, P->d_tot, d_res);
+  G16_HIP(hipGetLastError());
+  G16_HIP(hipStreamSynchronize(P->st));   // (E is a host temporary)
+  return G16_OK;
+}
+
+int random_fr(FrM* out) {
+  int fd = open("/dev/urandom", O_RDONLY);
+  if (fd < 0) { set_error("cannot open /dev/urandom"); return G16_E_STATE; }
+  Fr x;
+  for (;;) {
+    if (read(fd, x.v, 32) != 32) { close(fd); set_error("short read from /dev/urandom"); return G16_E_STATE; }
+    x.v[7] &= 0x3fffffffu;
+    if (h_lt_r(x.v)) break;
+  }
+  close(fd);
+  *out = fp_to_mont(x);
+  return G16_OK;
+}
+
+int plonk_prove_impl(g16_plonk* P, const uint8_t* wtns, size_t wlen, const uint8_t* blind, PlonkProofM* pr, uint8_t* pub) {
+  Sec s[16];
+  int rc = find_sections(wtns, wlen, "wtns", s, "wtns");
+  if (rc) return rc;
+  if (!s[1].p || s[1].size < 40 || !s[2].p) { set_error("wtns: Invalid File format"); return G16_E_FORMAT; }
+  {
+    static const uint32_t Rp[8] = G16_FR_P;
+    uint32_t n8;
+    memcpy(&n8, s[1].p, 4);
+    if (n8 != 32 || memcmp(s[1].p + 4, Rp, 32) != 0) {
+      set_error("Curve of the witness does not match the curve of the proving key");
+      return G16_E_FORMAT;
+    }
+    uint32_t nw;
+    memcpy(&nw, s[1].p + 36, 4);
+    if (nw != P->nBase) {
+      set_error("Invalid witness length. Circuit: " + std::to_string(P->nVars) + ", witness: " + std::to_string(nw) + ", " +
+                std::to_string(P->nAdd));
+      return G16_E_FORMAT;
+    }
+    if (s[2].size != (uint64_t)nw * 32) { set_error("wtns: Invalid File format"); return G16_E_FORMAT; }
+  }
+  for (uint32_t i = 0; i < P->nBase; i++) {
+    uint32_t v[8];
+    memcpy(v, s[2].p + (size_t)i * 32, 32);
+    if (!h_lt_r(v)) { set_error("wtns: signal " + std::to_string(i) + " is not reduced modulo the scalar field"); return G16_E_FORMAT; }
+  }
+  if (pub && P->nPublic) memcpy(pub, s[2].p + 32, (size_t)P->nPublic * 32);
+  FrM b[10];
+  b[0] = fp_zero<FrParams>();
+  for (int i = 1; i <= 9; i++) {
+    if (blind) {
+      Fr x;
+      memcpy(x.v, blind + (size_t)(i - 1) * 32, 32);
+      if (!h_lt_r(x.v)) { set_error("blinding scalar not below r"); return G16_E_ARG; }
+      b[i] = fp_to_mont(x);
+    } else if ((rc = random_fr(&b[i]))) {
+      return rc;
+    }
+  }
+  G16_HIP(hipSetDevice(P->device));
+  hipStream_t st = P->st;
+  const uint32_t N = P->N;
+  const size_t n4 = (size_t)N * 4;
+  // ---- witness: first element zeroed ("not used in plonk"), additions level by level, A/B/C
+  G16_HIP(hipMemcpyAsync(P->d_wraw, s[2].p, (size_t)P->nBase * 32, hipMemcpyHostToDevice, st));
+  k_to_mont<<<nblk(P->nBase), 256, 0, st>>>(P->d_wraw, P->d_w, P->nBase, 1u);
+  for (size_t l = 0; l + 1 < P->level_start.size(); l++) {
+    const uint32_t lo = P->level_start[l], hi = P->level_start[l + 1];
+    if (hi > lo)
+      k_additions<<<nblk(hi - lo), 256, 0, st>>>(P->d_add_order, lo, hi, P->d_add_s1, P->d_add_s2, P->d_add_f1, P->d_add_f2, P->d_w,
+                                                 P->nBase);
+  }
+  FrM* ev[3] = {P->d_A, P->d_B, P->d_C};
+  for (int c = 0; c < 3; c++) k_gather<<<nblk(N), 256, 0, st>>>(P->d_w, P->d_map[c], ev[c], N);
+  G16_HIP(hipGetLastError());
+  // ---- round 1
+  auto to4t = [&](const FrM* evals, Pz pz, FrM* pol, FrM* ext) -> int {
+    int r = do_ifft(P->ntt_n, evals, P->d_tmpN, P->d_lazy, st);
+    if (r) return r;
+    k_blind<<<nblk(N + pz.n), 256, 0, st>>>(P->d_tmpN, N, pz, pol);
+    k_pad4<<<nblk(n4), 256, 0, st>>>(P->d_tmpN, N, ext);
+    G16_HIP(hipGetLastError());
+    return do_fft(P->ntt_4n, ext, ext, P->d_lazy, st);
+  };
+  Pz pza{{b[2], b[1], fp_zero<FrParams>()}, 2}, pzb{{b[4], b[3], fp_zero<FrParams>()}, 2}, pzc{{b[6], b[5], fp_zero<FrParams>()}, 2};
+  if ((rc = to4t(P->d_A, pza, P->d_pa, P->d_A4))) return rc;
+  if ((rc = to4t(P->d_B, pzb, P->d_pb, P->d_B4))) return rc;
+  if ((rc = to4t(P->d_C, pzc, P->d_pc, P->d_C4))) return rc;
+  if ((rc = commit(P, P->d_pa, N + 2, &pr->A))) return rc;
+  if ((rc = commit(P, P->d_pb, N + 2, &pr->B))) return rc;
+  if ((rc = commit(P, P->d_pc, N + 2, &pr->C))) return rc;
+  // ---- round 2
+  std::vector<uint8_t> tr;
+  put_g1_be(tr, pr->A);
+  put_g1_be(tr, pr->B);
+  put_g1_be(tr, pr->C);
+  const FrM beta = hash_to_fr(tr);
+  tr.clear();
+  put_fr_be(tr, beta);
+  const FrM gamma = hash_to_fr(tr);
+  {
+    R2Args a{beta, gamma, P->k1, P->k2, P->w1};
+    const uint32_t nc = (N + kChunk - 1) / kChunk;
+    // num -> d_tmpN (ratios), den -> d_tmpN2, pre -> d_tmpN3, lp -> d_tmpN4
+    k_z_local<<<nblk(nc), 256, 0, st>>>(P->d_A, P->d_B, P->d_C, P->d_ext[5], P->d_ext[6], P->d_ext[7], a, N, P->d_tmpN, P->d_tmpN2,
+                                        P->d_tmpN3, P->d_tmpN4, P->d_tot);
+    G16_HIP(hipGetLastError());
+    G16_HIP(hipMemcpyAsync(P->h_tot.data(), P->d_tot, (size_t)nc * 32, hipMemcpyDeviceToHost, st));
+    G16_HIP(hipStreamSynchronize(st));
+    std::vector<FrM> carry(nc);
+    FrM run = fp_one<FrParams>();
+    for (uint32_t c = 0; c < nc; c++) {
+      carry[c] = run;
+      run = fp_mul(run, P->h_tot[c]);
+    }
+    if (!fp_eq(run, fp_one<FrParams>())) { set_error("Copy constraints does not match"); return G16_E_STATE; }
+    G16_HIP(hipMemcpyAsync(P->d_tot, carry.data(), (size_t)nc * 32, hipMemcpyHostToDevice, st));
+    k_z_apply<<<nblk(N), 256, 0, st>>>(P->d_tmpN4, P->d_tot, N, P->d_Z);
+    G16_HIP(hipGetLastError());
+    G16_HIP(hipStreamSynchronize(st));
+  }
+  Pz pzz{{b[9], b[8], b[7]}, 3};
+  if ((rc = to4t(P->d_Z, pzz, P->d_pz, P->d_Z4))) return rc;
+  if ((rc = commit(P, P->d_pz, N + 3, &pr->Z))) return rc;
+  // ---- round 3
+  tr.clear();
+  put_g1_be(tr, pr->Z);
+  const FrM alpha = hash_to_fr(tr);
+  {
+    // the public-input polynomial on the 4N domain
+    k_pi_evals<<<nblk(N), 256, 0, st>>>(P->d_A, P->nPublic, N, P->d_tmpN);
+    if ((rc = do_ifft(P->ntt_n, P->d_tmpN, P->d_tmpN2, P->d_lazy, st))) return rc;
+    k_pad4<<<nblk(n4), 256, 0, st>>>(P->d_tmpN2, N, P->d_pi4);
+    if ((rc = do_fft(P->ntt_4n, P->d_pi4, P->d_pi4, P->d_lazy, st))) return rc;
+    R3Args a;
+    a.beta = beta; a.gamma = gamma; a.alpha = alpha; a.alpha2 = fp_sqr(alpha); a.k1 = P->k1; a.k2 = P->k2; a.w1 = P->w1;
+    for (int i = 0; i < 10; i++) a.b[i] = b[i];
+    const FrM i4 = h_root(2), one = fp_one<FrParams>(), two = fp_add(one, one), zero = fp_zero<FrParams>();
+    const FrM m1 = fp_neg(one), m2 = fp_neg(two), four = fp_add(two, two), m8 = fp_neg(fp_add(four, four));
+    a.Z1[0] = zero; a.Z1[1] = fp_add(m1, i4); a.Z1[2] = m2; a.Z1[3] = fp_sub(m1, i4);
+    a.Z2[0] = zero; a.Z2[1] = fp_mul(m2, i4); a.Z2[2] = four; a.Z2[3] = fp_neg(fp_mul(m2, i4));
+    a.Z3[0] = zero; a.Z3[1] = fp_add(two, fp_mul(two, i4)); a.Z3[2] = m8; a.Z3[3] = fp_sub(two, fp_mul(two, i4));
+    R3Ptrs q{P->d_A4, P->d_B4, P->d_C4, P->d_Z4, P->d_ext[0], P->d_ext[1], P->d_ext[2], P->d_ext[3], P->d_ext[4],
+             P->d_ext[5], P->d_ext[6], P->d_ext[7], P->d_pi4, P->d_l1, P->d_om4};
+    k_round3<<<nblk(n4), 256, 0, st>>>(q, a, (uint32_t)n4, P->d_T, P->d_Tz);
+    G16_HIP(hipGetLastError());
+    if ((rc = do_ifft(P->ntt_4n, P->d_T, P->d_T, P->d_lazy, st))) return rc;
+    if ((rc = do_ifft(P->ntt_4n, P->d_Tz, P->d_Tz, P->d_lazy, st))) return rc;
+    G16_HIP(hipMemsetAsync(P->d_bad, 0, 8, st));
+    k_div_zh<<<nblk(N), 256, 0, st>>>(P->d_T, P->d_Tz, N, P->d_bad);
+    G16_HIP(hipGetLastError());
+    uint32_t bad[2] = {0, 0};
+    G16_HIP(hipMemcpyAsync(bad, P->d_bad, 8, hipMemcpyDeviceToHost, st));
+    G16_HIP(hipStreamSynchronize(st));
+    if (bad[0]) { set_error("T Polynomial is not divisible"); return G16_E_STATE; }
+    if (bad[1]) { set_error("Tz Polynomial is not well calculated"); return G16_E_STATE; }
+  }
+  if ((rc = commit(P, P->d_T, N, &pr->T1))) return rc;
+  if ((rc = commit(P, P->d_T + N, N, &pr->T2))) return rc;
+  if ((rc = commit(P, P->d_T + 2 * (size_t)N, N + 6, &pr->T3))) return rc;
+  // ---- round 4
+  tr.clear();
+  put_g1_be(tr, pr->T1);
+  put_g1_be(tr, pr->T2);
+  put_g1_be(tr, pr->T3);
+  const FrM xi = hash_to_fr(tr);
+  FrM et;
+  if ((rc = eval_pol(P, P->d_pa, N + 2, xi, &pr->ea))) return rc;
+  if ((rc = eval_pol(P, P->d_pb, N + 2, xi, &pr->eb))) return rc;
+  if ((rc = eval_pol(P, P->d_pc, N + 2, xi, &pr->ec))) return rc;
+  if ((rc = eval_pol(P, P->d_pol[5], N, xi, &pr->es1))) return rc;
+  if ((rc = eval_pol(P, P->d_pol[6], N, xi, &pr->es2))) return rc;
+  if ((rc = eval_pol(P, P->d_T, 3 * N + 6, xi, &et))) return rc;
+  const FrM xiw = fp_mul(xi, P->w1);
+  if ((rc = eval_pol(P, P->d_pz, N + 3, xiw, &pr->ezw))) return rc;
+  FrM xim = xi;
+  for (uint32_t i = 0; i < P->L; i++) xim = fp_sqr(xim);
+  {
+    const FrM one = fp_one<FrParams>();
+    const FrM bxi = fp_mul(beta, xi);
+    FrM e2 = fp_mul(fp_mul(fp_add(fp_add(pr->ea, bxi), gamma), fp_add(fp_add(pr->eb, fp_mul(bxi, P->k1)), gamma)),
+                    fp_add(fp_add(pr->ec, fp_mul(bxi, P->k2)), gamma));
+    e2 = fp_mul(e2, alpha);
+    FrM e3 = fp_mul(fp_add(fp_add(pr->ea, fp_mul(beta, pr->es1)), gamma), fp_add(fp_add(pr->eb, fp_mul(beta, pr->es2)), gamma));
+    e3 = fp_mul(fp_mul(fp_mul(e3, beta), pr->ezw), alpha);
+    const FrM l1 = fp_mul(fp_sub(xim, one), fp_inv(fp_mul(fp_sub(xi, one), h_from_u64(N))));
+    const FrM e4 = fp_mul(l1, fp_sqr(alpha));
+    R4Args a{fp_add(e2, e4), fp_mul(pr->ea, pr->eb), pr->ea, pr->eb, pr->ec, e3};
+    k_pol_r<<<nblk(N + 3), 256, 0, st>>>(P->d_pz, P->d_pol[0], P->d_pol[1], P->d_pol[2], P->d_pol[3], P->d_pol[4], P->d_pol[7], a, N,
+                                         P->d_r);
+    G16_HIP(hipGetLastError());
+  }
+  if ((rc = eval_pol(P, P->d_r, N + 3, xi, &pr->er))) return rc;
+  // ---- round 5
+  tr.clear();
+  put_fr_be(tr, pr->ea); put_fr_be(tr, pr->eb); put_fr_be(tr, pr->ec); put_fr_be(tr, pr->es1); put_fr_be(tr, pr->es2);
+  put_fr_be(tr, pr->ezw); put_fr_be(tr, pr->er);
+  R5Args a5;
+  a5.v[0] = fp_zero<FrParams>();
+  a5.v[1] = hash_to_fr(tr);
+  for (int i = 2; i <= 6; i++) a5.v[i] = fp_mul(a5.v[i - 1], a5.v[1]);
+  a5.xim = xim;
+  a5.xi2m = fp_sqr(xim);
+  a5.sub0 = fp_add(et, fp_add(fp_mul(a5.v[1], pr->er),
+                   fp_add(fp_mul(a5.v[2], pr->ea), fp_add(fp_mul(a5.v[3], pr->eb), fp_add(fp_mul(a5.v[4], pr->ec),
+                   fp_add(fp_mul(a5.v[5], pr->es1), fp_mul(a5.v[6], pr->es2)))))));
+  k_pol_wxi<<<nblk(N + 6), 256, 0, st>>>(P->d_T, P->d_r, P->d_pa, P->d_pb, P->d_pc, P->d_pol[5], P->d_pol[6], a5, N, P->d_wxi);
+  G16_HIP(hipGetLastError());
+  if ((rc = div_pol1(P, P->d_wxi, N + 6, xi, P->d_q))) return rc;
+  if ((rc = commit(P, P->d_q, N + 6, &pr->Wxi))) return rc;
+  G16_HIP(hipMemcpyAsync(P->d_wxi, P->d_pz, ((size_t)N + 3) * 32, hipMemcpyDeviceToDevice, st));
+  k_sub0<<<1, 1, 0, st>>>(P->d_wxi, pr->ezw);
+  if ((rc = div_pol1(P, P->d_wxi, N + 3, xiw, P->d_q))) return rc;
+  if ((rc = commit(P, P->d_q, N + 3, &pr->Wxiw))) return rc;
+  return G16_OK;
+}
+
+}  // namespace
+
+// setup helper (synth.cpp::g16_plonk_setup): for each of 8 evaluation vectors (N Montgomery words on the host), the N
+// coefficients and the 4N evaluations, written back to back at out[k] (5N words)
+namespace g16 {
+int plonk_setup_polys(int device, int L, const Fr* const evals[8], uint8_t* const out[8]) {
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { set_error("plonk setup: no HIP device (the transforms run on the GPU)"); return G16_E_NOGPU; }
+  if (device < 0 || device >= ndev) { set_error("plonk setup: bad device ordinal"); return G16_E_ARG; }
+  G16_HIP(hipSetDevice(device));
+  const size_t N = (size_t)1 << L, n4 = N * 4;
+  NttTables tn, t4;
+  hipStream_t st = nullptr;
+  FrM *d_ev = nullptr, *d_co = nullptr, *d_ext = nullptr;
+  F29* d_lazy = nullptr;
+  int rc = G16_OK;
+  auto fail = [&](hipError_t e) {
+    if (e == hipSuccess) return false;
+    set_error(std::string("plonk setup: ") + hipGetErrorString(e));
+    rc = G16_E_HIP;
+    return true;
+  };
+  do {
+    if (fail(hipStreamCreate(&st))) break;
+    if ((rc = ntt_tables_create(tn, L, st))) break;
+    if ((rc = ntt_tables_create(t4, L + 2, st))) break;
+    if (fail(hipMalloc(&d_ev, N * 32)) || fail(hipMalloc(&d_co, N * 32)) || fail(hipMalloc(&d_ext, n4 * 32)) ||
+        fail(hipMalloc(&d_lazy, n4 * sizeof(F29)))) break;
+    for (int k = 0; k < 8 && rc == G16_OK; k++) {
+      if (fail(hipMemcpyAsync(d_ev, evals[k], N * 32, hipMemcpyHostToDevice, st))) break;
+      if ((rc = do_ifft(tn, d_ev, d_co, d_lazy, st))) break;
+      k_pad4<<<nblk(n4), 256, 0, st>>>(d_co, (uint32_t)N, d_ext);
+      if ((rc = do_fft(t4, d_ext, d_ext, d_lazy, st))) break;
+      if (fail(hipGetLastError())) break;
+      if (fail(hipMemcpyAsync(out[k], d_co, N * 32, hipMemcpyDeviceToHost, st))) break;
+      if (fail(hipMemcpyAsync(out[k] + N * 32, d_ext, n4 * 32, hipMemcpyDeviceToHost, st))) break;
+      if (fail(hipStreamSynchronize(st))) break;
+    }
+  } while (false);
+  if (st) (void)hipStreamSynchronize(st);
+  void* bufs[] = {d_ev, d_co, d_ext, d_lazy};
+  for (void* p : bufs) if (p) (void)hipFree(p);
+  ntt_tables_destroy(tn);
+  ntt_tables_destroy(t4);
+  if (st) (void)hipStreamDestroy(st);
+  return rc;
+}
+}  // namespace g16
+
+namespace {
+
+void g1_std(uint8_t out[64], const G1Affine& p) {
+  if (aff_is_inf(p)) { memset(out, 0, 64); return; }
+  const Fq x = fp_from_mont(p.x), y = fp_from_mont(p.y);
+  memcpy(out, x.v, 32);
+  memcpy(out + 32, y.v, 32);
+}
+
+}  // namespace
+
+extern "C" int g16_plonk_create(const uint8_t* zkey, size_t zkey_len, int device, g16_plonk** out) {
+  if (!zkey || !out) { set_error("NULL argument"); return G16_E_ARG; }
+  g16_plonk* P = new g16_plonk();
+  const int rc = plonk_create_impl(zkey, zkey_len, device, P);
+  if (rc) { delete P; return rc; }
+  *out = P;
+  return G16_OK;
+}
+
+extern "C" int g16_plonk_prove(g16_plonk* P, const uint8_t* wtns, size_t wtns_len, const uint8_t* blinding,
+                               g16_plonk_proof* out, uint8_t* pub) {
+  if (!P || !wtns || !out) { set_error("NULL argument"); return G16_E_ARG; }
+  std::lock_guard<std::mutex> lk(P->mu);
+  PlonkProofM pr;
+  const int rc = plonk_prove_impl(P, wtns, wtns_len, blinding, &pr, pub);
+  if (rc) return rc;
+  g1_std(out->A, pr.A); g1_std(out->B, pr.B); g1_std(out->C, pr.C); g1_std(out->Z, pr.Z);
+  g1_std(out->T1, pr.T1); g1_std(out->T2, pr.T2); g1_std(out->T3, pr.T3); g1_std(out->Wxi, pr.Wxi); g1_std(out->Wxiw, pr.Wxiw);
+  const FrM* evs[7] = {&pr.ea, &pr.eb, &pr.ec, &pr.es1, &pr.es2, &pr.ezw, &pr.er};
+  uint8_t* dst[7] = {out->eval_a, out->eval_b, out->eval_c, out->eval_s1, out->eval_s2, out->eval_zw, out->eval_r};
+  for (int k = 0; k < 7; k++) {
+    const Fr sdt = fp_from_mont(*evs[k]);
+    memcpy(dst[k], sdt.v, 32);
+  }
+  return G16_OK;
+}
+
+extern "C" int g16_plonk_get_info(const g16_plonk* P, uint32_t info[6]) {
+  if (!P || !info) { set_error("NULL argument"); return G16_E_ARG; }
+  info[0] = P->nVars; info[1] = P->nPublic; info[2] = P->N; info[3] = P->nAdd; info[4] = P->nCons;
+  info[5] = (uint32_t)(P->level_start.empty() ? 0 : P->level_start.size() - 1);
+  return G16_OK;
+}
+
+extern "C" void g16_plonk_destroy(g16_plonk* P) { delete P; }

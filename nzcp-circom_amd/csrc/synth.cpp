@@ -1155,6 +1155,239 @@ extern "C" int g16_r1cs_setup(const uint8_t* r1cs, size_t r1cs_len, uint64_t see
   return setup_core(c, seed, threads, zkey, zkey_len, vkey, vkey_len);
 }
 
+// ------------------------------------------------------------------ PLONK setup (test-only: tau is known)
+// Stands in for `snarkjs plonk setup c.r1cs pot.ptau c.zkey` (/root/reference/Makefile:31; [EXT] snarkjs 0.4.12
+// plonk_setup.js): R1CS -> PLONK gates as snarkjs does it (public-input gates first; linear combinations reduced to
+// one signal by addition gates taken from the front of a queue, results appended), copy-constraint permutation,
+// selector / sigma polynomials as N coefficients + 4N evaluations, N + 6 powers of tau -- here from a KNOWN tau
+// (seed), so the commitments are [Q(tau)]G by one fixed-base multiplication each.  Restated in oracle/plonk.py::setup,
+// whose zkey this must equal byte for byte for the same tau (tests/test_gpu_plonk.py).  The transforms run on the
+// device (plonk.hip::plonk_setup_polys); with_lagrange = 0 writes an EMPTY section 13.
+namespace g16 {
+namespace {
+
+struct PlonkGate { uint32_t sl, sr, so; FrM qm, ql, qr, qo, qc; };
+struct PlonkAdd { uint32_t s1, s2; FrM f1, f2; };
+
+struct PlonkBuilder {
+  std::vector<PlonkGate> gates;
+  std::vector<PlonkAdd> adds;
+  uint32_t nv = 0;
+  FrM zero = fp_zero<FrParams>(), one = fr_one();
+  struct LC { FrM k; std::vector<Term> t; };   // constant + terms on distinct non-zero wires (first-appearance order)
+  // merge duplicate wires, split the constant off, drop zero coefficients; keeps the order of first appearance (what
+  // iterating a JS object with integer keys does NOT do -- snarkjs walks ascending signal ids -- so sort by id)
+  LC lc_of(const Term* b, const Term* e) {
+    LC r;
+    r.k = zero;
+    std::vector<Term> v(b, e);
+    std::sort(v.begin(), v.end(), [](const Term& x, const Term& y) { return x.s < y.s; });
+    size_t i = 0;
+    while (i < v.size()) {
+      FrM sum = zero;
+      const uint32_t wire = v[i].s;
+      while (i < v.size() && v[i].s == wire) sum = fp_add(sum, v[i++].cf);
+      if (fp_is_zero(sum)) continue;
+      if (wire == 0) r.k = sum;
+      else r.t.push_back({wire, sum});
+    }
+    return r;
+  }
+  // reduceCoefs: while more than max_c terms, the first two become one addition gate whose output goes to the back
+  void reduce(LC& lc, size_t max_c) {
+    size_t head = 0;
+    while (lc.t.size() - head > max_c) {
+      const Term c1 = lc.t[head], c2 = lc.t[head + 1];
+      head += 2;
+      const uint32_t so = nv++;
+      gates.push_back({c1.s, c2.s, so, zero, fp_neg(c1.cf), fp_neg(c2.cf), one, zero});
+      adds.push_back({c1.s, c2.s, c1.cf, c2.cf});
+      lc.t.push_back({so, one});
+    }
+    lc.t.erase(lc.t.begin(), lc.t.begin() + head);
+    while (lc.t.size() < max_c) lc.t.push_back({0u, zero});
+  }
+  void add_sum(LC lc) {
+    reduce(lc, 3);
+    gates.push_back({lc.t[0].s, lc.t[1].s, lc.t[2].s, zero, lc.t[0].cf, lc.t[1].cf, lc.t[2].cf, lc.k});
+  }
+};
+
+}  // namespace
+// plonk.hip
+int plonk_setup_polys(int device, int L, const Fr* const evals[8], uint8_t* const out[8]);
+}  // namespace g16
+
+extern "C" int g16_plonk_setup(const uint8_t* r1cs, size_t r1cs_len, uint64_t seed, int device, int with_lagrange,
+                               uint8_t** zkey, size_t* zkey_len) {
+  if (!r1cs || !zkey || !zkey_len) { set_error("NULL argument"); return G16_E_ARG; }
+  Circuit c;
+  int rc = read_r1cs(r1cs, r1cs_len, c);
+  if (rc) return rc;
+  PlonkBuilder pb;
+  pb.nv = c.n;
+  for (uint32_t s = 1; s <= c.p; s++) pb.gates.push_back({s, 0u, 0u, pb.zero, pb.one, pb.zero, pb.zero, pb.zero});
+  for (uint32_t r = 0; r < c.m; r++) {
+    PlonkBuilder::LC a = pb.lc_of(c.tA.data() + c.rowA[r], c.tA.data() + c.rowA[r + 1]);
+    PlonkBuilder::LC b = pb.lc_of(c.tB.data() + c.rowB[r], c.tB.data() + c.rowB[r + 1]);
+    PlonkBuilder::LC cc = pb.lc_of(c.tC.data() + c.rowC[r], c.tC.data() + c.rowC[r + 1]);
+    const bool a0 = a.t.empty() && fp_is_zero(a.k), b0 = b.t.empty() && fp_is_zero(b.k);
+    if (a0 || b0) {
+      pb.add_sum(cc);
+    } else if (a.t.empty() || b.t.empty()) {   // a constant times a linear combination: k * other - C = 0
+      const FrM kk = a.t.empty() ? a.k : b.k;
+      const PlonkBuilder::LC& other = a.t.empty() ? b : a;
+      std::vector<Term> j;
+      j.push_back({0u, fp_sub(fp_mul(kk, other.k), cc.k)});
+      for (const Term& t : other.t) j.push_back({t.s, fp_mul(kk, t.cf)});
+      for (const Term& t : cc.t) j.push_back({t.s, fp_neg(t.cf)});
+      pb.add_sum(pb.lc_of(j.data(), j.data() + j.size()));
+    } else {
+      pb.reduce(a, 1);
+      pb.reduce(b, 1);
+      pb.reduce(cc, 1);
+      pb.gates.push_back({a.t[0].s, b.t[0].s, cc.t[0].s, fp_mul(a.t[0].cf, b.t[0].cf), fp_mul(a.t[0].cf, b.k),
+                          fp_mul(a.k, b.t[0].cf), fp_neg(cc.t[0].cf), fp_sub(fp_mul(a.k, b.k), cc.k)});
+    }
+  }
+  const size_t ng = pb.gates.size();
+  int L = 2;
+  while (((size_t)1 << L) < ng) L++;
+  if (L > 24) { set_error("plonk setup: circuit too large (more than 2^24 gates)"); return G16_E_ARG; }
+  const size_t N = (size_t)1 << L;
+  Xo trng(seed + 1);
+  FrM tau;
+  do { tau = trng.rand_fr(); } while (fp_is_zero(tau));
+  const FrM w1 = host_root(L);
+  // k1, k2: smallest values whose cosets are disjoint from H and from each other
+  auto pow_n = [&](FrM x) { for (int i = 0; i < L; i++) x = fp_sqr(x); return x; };
+  const FrM one = fr_one();
+  uint64_t k1v = 2;
+  while (fp_eq(pow_n(fr_u64(k1v)), one)) k1v++;
+  uint64_t k2v = k1v + 1;
+  while (fp_eq(pow_n(fr_u64(k2v)), one) || fp_eq(pow_n(fp_mul(fr_u64(k2v), fp_inv(fr_u64(k1v)))), one)) k2v++;
+  const FrM k1 = fr_u64(k1v), k2 = fr_u64(k2v);
+  // evaluation vectors: 5 selectors, 3 sigmas
+  std::vector<std::vector<Fr>> ev(8, std::vector<Fr>(N, fp_zero<FrParams>()));
+  std::vector<uint32_t> maps[3];
+  for (auto& m : maps) m.assign(N, 0u);
+  for (size_t i = 0; i < ng; i++) {
+    const PlonkGate& g = pb.gates[i];
+    maps[0][i] = g.sl; maps[1][i] = g.sr; maps[2][i] = g.so;
+    ev[0][i] = g.qm; ev[1][i] = g.ql; ev[2][i] = g.qr; ev[3][i] = g.qo; ev[4][i] = g.qc;
+  }
+  {
+    std::vector<FrM> last(pb.nv);
+    std::vector<uint32_t> first(pb.nv, 0xffffffffu);
+    std::vector<uint8_t> seen(pb.nv, 0);
+    FrM w = one;
+    for (size_t i = 0; i < N; i++) {
+      const FrM vals[3] = {w, fp_mul(w, k1), fp_mul(w, k2)};
+      for (int col = 0; col < 3; col++) {
+        const uint32_t sgn = maps[col][i];
+        const size_t ppos = (size_t)col * N + i;
+        if (seen[sgn]) ev[5 + col][i] = last[sgn];
+        else { first[sgn] = (uint32_t)ppos; seen[sgn] = 1; }
+        last[sgn] = vals[col];
+      }
+      w = fp_mul(w, w1);
+    }
+    for (uint32_t sgn = 0; sgn < pb.nv; sgn++)
+      if (seen[sgn]) ev[5 + first[sgn] / N][first[sgn] % N] = last[sgn];
+  }
+  // file image
+  const size_t nlag = with_lagrange ? (c.p > 0 ? c.p : 1) : 0;
+  const size_t polb = N * 32 * 5;
+  const size_t hdr = 4 + 32 + 4 + 32 + 20 + 64 + 8 * 64 + 128;
+  const size_t sizes[15] = {0, 4, hdr, pb.adds.size() * 72, ng * 4, ng * 4, ng * 4, polb, polb, polb, polb, polb, 3 * polb,
+                            nlag * polb, (N + 6) * 64};
+  size_t total = 12;
+  for (int i = 1; i <= 14; i++) total += 12 + sizes[i];
+  Buf z;
+  if (!z.reserve(total)) { set_error("plonk setup: out of memory"); return G16_E_STATE; }
+  z.put("zkey", 4); z.u32(1); z.u32(14);
+  uint8_t* sp[15] = {};
+  for (uint32_t id = 1; id <= 14; id++) { z.u32(id); z.u64(sizes[id]); sp[id] = z.skip(sizes[id]); }
+  { uint32_t two = 2; memcpy(sp[1], &two, 4); }
+  for (size_t k = 0; k < pb.adds.size(); k++) {
+    uint8_t* q = sp[3] + k * 72;
+    memcpy(q, &pb.adds[k].s1, 4); memcpy(q + 4, &pb.adds[k].s2, 4);
+    memcpy(q + 8, pb.adds[k].f1.v, 32); memcpy(q + 40, pb.adds[k].f2.v, 32);
+  }
+  for (int col = 0; col < 3; col++) memcpy(sp[4 + col], maps[col].data(), ng * 4);
+  // polynomials on the device: coefficients + 4N evaluations straight into the sections
+  {
+    const Fr* evp[8];
+    uint8_t* outp[8];
+    for (int k = 0; k < 8; k++) {
+      evp[k] = ev[k].data();
+      outp[k] = k < 5 ? sp[7 + k] : sp[12] + (size_t)(k - 5) * polb;
+    }
+    if ((rc = plonk_setup_polys(device, L, evp, outp))) { free(z.p); return rc; }
+    if (nlag) {   // Lagrange polynomials of the public inputs, 8 at a time
+      std::vector<std::vector<Fr>> le(8, std::vector<Fr>(N));
+      for (size_t j0 = 0; j0 < nlag; j0 += 8) {
+        for (int k = 0; k < 8; k++) {
+          std::fill(le[k].begin(), le[k].end(), fp_zero<FrParams>());
+          const size_t j = j0 + k < nlag ? j0 + k : nlag - 1;
+          le[k][j] = one;
+          evp[k] = le[k].data();
+          outp[k] = sp[13] + j * polb;
+        }
+        if ((rc = plonk_setup_polys(device, L, evp, outp))) { free(z.p); return rc; }
+      }
+    }
+  }
+  // powers of tau and the commitments [P(tau)]G (tau is known: one fixed-base multiplication each)
+  const int threads = (int)std::thread::hardware_concurrency() > 0 ? (int)std::thread::hardware_concurrency() : 1;
+  FixedBase<FqOps> fb1;
+  FixedBase<Fq2Ops> fb2;
+  G1Affine g1;
+  g1.x = fp_one<FqParams>();
+  g1.y = fp_add(g1.x, g1.x);
+  G2Affine g2;
+  g2.x.a = Fq{G16_G2X0}; g2.x.b = Fq{G16_G2X1}; g2.y.a = Fq{G16_G2Y0}; g2.y.b = Fq{G16_G2Y1};
+  build_table(fb1, g1, 8, threads);
+  build_table(fb2, g2, 8, threads);
+  {
+    std::vector<FrM> pw(N + 6);
+    FrM x = one;
+    for (size_t i = 0; i < N + 6; i++) { pw[i] = x; x = fp_mul(x, tau); }
+    if (device >= 0) {
+      if ((rc = setup_fixed_mul_g1(device, fb1.tbl.data(), fb1.wb, fb1.nwin, pw.data(), N + 6, sp[14]))) { free(z.p); return rc; }
+    } else {
+      fixed_mul_many(fb1, pw.data(), N + 6, sp[14], threads);
+    }
+  }
+  {
+    uint8_t* q = sp[2];
+    static const uint32_t Qp[8] = G16_FQ_P, Rp[8] = G16_FR_P;
+    uint32_t v32 = 32;
+    memcpy(q, &v32, 4); memcpy(q + 4, Qp, 32); memcpy(q + 36, &v32, 4); memcpy(q + 40, Rp, 32);
+    q += 72;
+    const uint32_t hv[5] = {pb.nv, c.p, (uint32_t)N, (uint32_t)pb.adds.size(), (uint32_t)ng};
+    memcpy(q, hv, 20); q += 20;
+    memcpy(q, k1.v, 32); memcpy(q + 32, k2.v, 32); q += 64;
+    FrM cm[8];
+    for (int k = 0; k < 8; k++) {   // P(tau) by Horner over the coefficients just written
+      const uint8_t* co = k < 5 ? sp[7 + k] : sp[12] + (size_t)(k - 5) * polb;
+      FrM acc = fp_zero<FrParams>();
+      for (size_t i = N; i-- > 0;) {
+        FrM cf;
+        memcpy(cf.v, co + i * 32, 32);
+        acc = fp_add(fp_mul(acc, tau), cf);
+      }
+      cm[k] = acc;
+    }
+    fixed_mul_many(fb1, cm, 8, q, 1);
+    q += 8 * 64;
+    fixed_mul_many(fb2, &tau, 1, q, 1);
+  }
+  *zkey = z.p;
+  *zkey_len = z.len;
+  return G16_OK;
+}
+
 extern "C" int g16_setup_device(int device) {
   if (device < -1) { set_error("setup: bad device ordinal"); return G16_E_ARG; }
   g_setup_device.store(device);

@@ -452,3 +452,59 @@ def verify(vk, public, proof):
     lhs = G1.add(proof["Wxi"], G1.mul(proof["Wxiw"], u))
     rhs = G1.add(G1.add(G1.mul(proof["Wxi"], xi), G1.mul(proof["Wxiw"], u * xi % R * w1 % R)), G1.add(F, G1.neg(E)))
     return pairing_product_is_one([(lhs, vk["X_2"]), (G1.neg(rhs), G2_GEN)])
+
+
+# ------------------------------------------------------------------ PLONK .zkey (snarkjs 0.4.12 zkey_utils.js writePlonk / readHeaderPlonk)
+def write_zkey(zk, with_lagrange=True):
+    """Sections: 1 protocol id (2), 2 header, 3 additions, 4-6 the A/B/C signal maps, 7-11 Qm Ql Qr Qo Qc, 12 sigma 1-3,
+    13 Lagrange polynomials of the public inputs, 14 powers of tau; a polynomial = N coefficients + 4N evaluations;
+    field elements as Montgomery residues, points affine Montgomery.  with_lagrange=False writes an EMPTY section 13
+    (a prover that derives the public-input polynomial by NTT does not read it; 513 public signals at N = 2^22 would
+    be 344 GB)."""
+    import struct
+    from bn254 import Q, RR
+    from formats import le, g1_to_lem, g2_to_lem, write_binfile, N8
+
+    def fr(x):
+        return le(x * RR % R)
+
+    def poly(c, e4):
+        return b"".join(fr(x) for x in c) + b"".join(fr(x) for x in e4)
+    n = zk["domainSize"]
+    s2 = (struct.pack("<I", N8) + le(Q) + struct.pack("<I", N8) + le(R) +
+          struct.pack("<IIIII", zk["nVars"], zk["nPublic"], n, zk["nAdditions"], zk["nConstraints"]) +
+          fr(zk["k1"]) + fr(zk["k2"]) + b"".join(g1_to_lem(zk[k]) for k in ("Qm", "Ql", "Qr", "Qo", "Qc", "S1", "S2", "S3")) +
+          g2_to_lem(zk["X_2"]))
+    s3 = b"".join(struct.pack("<II", s1, s2_) + fr(f1) + fr(f2) for s1, s2_, f1, f2 in zk["additions"])
+    nc = zk["nConstraints"]
+    maps = [b"".join(struct.pack("<I", s) for s in zk["maps"][c][:nc]) for c in range(3)]
+    secs = [(1, struct.pack("<I", 2)), (2, s2), (3, s3), (4, maps[0]), (5, maps[1]), (6, maps[2])]
+    for sid, name in zip(range(7, 12), ("Qm", "Ql", "Qr", "Qo", "Qc")):
+        secs.append((sid, poly(zk["pol_" + name], zk["ext_" + name])))
+    secs.append((12, b"".join(poly(zk["pol_S%d" % k], zk["ext_S%d" % k]) for k in (1, 2, 3))))
+    secs.append((13, b"".join(poly(c, e4) for c, e4 in zk["lagrange"]) if with_lagrange else b""))
+    secs.append((14, b"".join(g1_to_lem(P) for P in zk["srs"])))
+    return write_binfile("zkey", 1, secs)
+
+
+def proof_obj(proof):
+    """The object `snarkjs plonk prove` stringifies (key order of plonk_prove.js)."""
+    def g1(P):
+        return ["0", "1", "0"] if P is None else [str(P[0]), str(P[1]), "1"]
+    o = {}
+    for k in ("A", "B", "C", "Z", "T1", "T2", "T3"):
+        o[k] = g1(proof[k])
+    for k in ("a", "b", "c", "s1", "s2", "zw", "r"):
+        o["eval_" + k] = str(proof["eval_" + k])
+    o["Wxi"], o["Wxiw"] = g1(proof["Wxi"]), g1(proof["Wxiw"])
+    o["protocol"], o["curve"] = "plonk", "bn128"
+    return o
+
+
+def proof_from_obj(o):
+    def g1(t):
+        return None if str(t[2]) == "0" else (int(t[0]), int(t[1]))
+    p = {k: g1(o[k]) for k in ("A", "B", "C", "Z", "T1", "T2", "T3", "Wxi", "Wxiw")}
+    for k in ("a", "b", "c", "s1", "s2", "zw", "r"):
+        p["eval_" + k] = int(o["eval_" + k])
+    return p

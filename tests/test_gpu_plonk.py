@@ -1,0 +1,75 @@
+"""SURVEY 8f row 4, PLONK prover: the device prover (csrc/plonk.hip) through the C ABI against oracle/plonk.py on the
+SAME zkey (written by the oracle in snarkjs's PLONK layout), witness and blinding scalars b1..b9 -- the proof must be
+the oracle's proof bit for bit (every commitment, every evaluation), and the oracle's KZG verifier must accept it."""
+import pytest
+
+import bn254 as b
+import formats as f
+import plonk as pk
+import synth
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("n,p,m,seed", [(24, 2, 12, 1), (60, 5, 40, 3), (300, 20, 260, 9), (700, 513, 150, 4)])
+def test_proof_equals_oracle(amd, n, p, m, seed):
+    rows, w = synth.make(n, p, m, seed)
+    zk = pk.setup(n, p, rows, tau=0xabcdef + seed)
+    zkey = pk.write_zkey(zk, with_lagrange=(seed % 2 == 1))      # the prover does not read section 13
+    wtns = f.write_wtns(w)
+    rng = synth.Xoshiro(seed + 40)
+    bl = {i: rng.rand_fr() for i in range(1, 10)}
+    prover = amd.PlonkProver(zkey, device=0)
+    assert (prover.n_public, prover.domain_size, prover.n_additions) == (p, zk["domainSize"], zk["nAdditions"])
+    proof, pub = prover.prove(wtns, [bl[i] for i in range(1, 10)])
+    exp, exp_pub = pk.prove(zk, w, bl)
+    assert proof == pk.proof_obj(exp)
+    assert pub == [str(x) for x in exp_pub]
+    assert pk.verify(pk.vkey(zk), [int(x) for x in pub], pk.proof_from_obj(proof))
+    # random blinding: another proof, accepted as well; a second witness of the same circuit
+    proof2, pub2 = prover.prove(wtns)
+    assert proof2["A"] != proof["A"] and pk.verify(pk.vkey(zk), [int(x) for x in pub2], pk.proof_from_obj(proof2))
+    w3 = synth.make(n, p, m, seed, 777)[1]
+    proof3, pub3 = prover.prove(f.write_wtns(w3), [bl[i] for i in range(1, 10)])
+    assert proof3 == pk.proof_obj(pk.prove(zk, w3, bl)[0])
+    prover.close()
+
+
+def test_plonk_errors(amd):
+    rows, w = synth.make(24, 2, 12, 1)
+    zk = pk.setup(24, 2, rows, tau=99)
+    zkey = pk.write_zkey(zk)
+    with pytest.raises(amd.G16Error) as e:
+        amd.PlonkProver(open(__import__("conftest").golden_path("tiny.zkey"), "rb").read())
+    assert "zkey file is not plonk" in str(e.value)
+    with pytest.raises(amd.G16Error) as e:
+        amd.PlonkProver(zkey[:300])
+    assert "Invalid File format" in str(e.value)
+    prover = amd.PlonkProver(zkey)
+    with pytest.raises(amd.G16Error) as e:
+        prover.prove(f.write_wtns(w[:-1]))
+    assert "Invalid witness length. Circuit: %d, witness: %d, %d" % (zk["nVars"], len(w) - 1, zk["nAdditions"]) in str(e.value)
+    bad = list(w)
+    bad[len(w) - 1] = (bad[len(w) - 1] + 1) % b.R           # breaks a gate: the quotient is no polynomial
+    with pytest.raises(amd.G16Error) as e:
+        prover.prove(f.write_wtns(bad))
+    assert "not divisible" in str(e.value) or "Copy constraints" in str(e.value) or "does not divide" in str(e.value)
+    prover.close()
+
+
+@pytest.mark.parametrize("n,p,m,seed,lag", [(24, 2, 12, 1, True), (300, 20, 260, 9, True), (700, 513, 150, 4, False)])
+def test_setup_tool_equals_oracle(amd, n, p, m, seed, lag):
+    """g16_plonk_setup (R1CS -> gates on the host, transforms and powers of tau on the device) writes the zkey
+    oracle/plonk.py::setup + write_zkey write for the same tau, byte for byte -- and that key proves."""
+    import groth16 as g
+    _, rows, _ = synth.gen_circuit(n, p, m, seed)
+    r1cs = f.write_r1cs(n, p, 0, rows)
+    zkey = amd.plonk_setup(r1cs, seed, device=0, with_lagrange=lag)
+    rows_w, w = synth.make(n, p, m, seed)
+    tau = g.trapdoor(seed + 1)["tau"]
+    zk = pk.setup(n, p, rows_w, tau)
+    assert zkey == pk.write_zkey(zk, with_lagrange=lag)
+    prover = amd.PlonkProver(zkey, device=0)
+    proof, pub = prover.prove(f.write_wtns(w))
+    prover.close()
+    assert pk.verify(pk.vkey(zk), [int(x) for x in pub], pk.proof_from_obj(proof))
