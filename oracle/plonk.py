@@ -91,7 +91,8 @@ def r1cs_to_plonk(n_vars, n_public, rows):
         d = {}
         for wire, cf in terms:
             d[wire] = (d.get(wire, 0) + cf) % R
-        return {s: c for s, c in d.items() if c}
+        # (snarkjs keeps a linear combination as a JS object keyed by signal id: iteration is in ascending id order)
+        return {s: d[s] for s in sorted(d) if d[s]}
 
     def reduce_coefs(lc, max_c):
         k = lc.get(0, 0)
@@ -127,7 +128,7 @@ def r1cs_to_plonk(n_vars, n_public, rows):
             j = {s: (-v) % R for s, v in j.items()}
             for s, v in other.items():
                 j[s] = (j.get(s, 0) + kk * v) % R
-            add_sum({s: v for s, v in j.items() if v})
+            add_sum({s: j[s] for s in sorted(j) if j[s]})
         else:
             ka, sa, ca = reduce_coefs(a, 1)
             kb, sb, cb = reduce_coefs(b, 1)
