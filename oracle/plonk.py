@@ -509,3 +509,25 @@ def proof_from_obj(o):
     for k in ("a", "b", "c", "s1", "s2", "zw", "r"):
         p["eval_" + k] = int(o["eval_" + k])
     return p
+
+
+def vkey_from_zkey(buf):
+    """The verification key `snarkjs zkey export verificationkey` reads from a PLONK .zkey header (section 2)."""
+    import struct
+    from bn254 import RR
+    from formats import read_binfile, section, g1_from_lem, g2_from_lem, from_le
+    secs = read_binfile(buf, "zkey", 2, "zkey")
+    h = section(buf, secs, 2)
+    pos = 72
+    n_vars, n_public, n, n_add, n_cons = struct.unpack_from("<IIIII", h, pos)
+    pos += 20
+    rinv = pow(RR, -1, R)
+    k1 = from_le(h[pos:pos + 32]) * rinv % R
+    k2 = from_le(h[pos + 32:pos + 64]) * rinv % R
+    pos += 64
+    vk = {"protocol": "plonk", "nPublic": n_public, "power": n.bit_length() - 1, "k1": k1, "k2": k2}
+    for name in ("Qm", "Ql", "Qr", "Qo", "Qc", "S1", "S2", "S3"):
+        vk[name] = g1_from_lem(h[pos:pos + 64])
+        pos += 64
+    vk["X_2"] = g2_from_lem(h[pos:pos + 128])
+    return vk
