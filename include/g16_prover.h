@@ -306,6 +306,8 @@ int g16_plonk_prove(g16_plonk* p, const uint8_t* wtns, size_t wtns_len, const ui
                     g16_plonk_proof* out, uint8_t* pub);
 /* info: nVars (with the addition signals), nPublic, domainSize, nAdditions, nConstraints, addition dependency levels */
 int g16_plonk_get_info(const g16_plonk* p, uint32_t info[6]);
+/* host wall time of the last proof, ms: [0] witness + round 1, [1] round 2, [2] round 3, [3] round 4, [4] round 5, [5] total */
+int g16_plonk_timings(const g16_plonk* p, float ms[6]);
 void g16_plonk_destroy(g16_plonk* p);
 /* Test-only stand-in for `snarkjs plonk setup c.r1cs pot.ptau c.zkey` (/root/reference/Makefile:31) with a KNOWN tau
  * (derived from seed): iden3 .r1cs v1 in, snarkjs-layout PLONK .zkey out (g16_free).  R1CS -> gates as plonk_setup.js

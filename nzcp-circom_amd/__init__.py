@@ -66,7 +66,7 @@ EXPORTS = ["g16_create", "g16_prove", "g16_prove_batch", "g16_stage_witness", "g
            "g16_multi_create", "g16_multi_prove", "g16_multi_get_info", "g16_multi_destroy",
            "g16_nzcp_gadget", "g16_nzcp_circuit_setup", "g16_setup_device",
            "g16_verifier_create", "g16_verify_batch", "g16_verifier_timings", "g16_verifier_destroy", "g16_pairing_op",
-           "g16_plonk_create", "g16_plonk_prove", "g16_plonk_get_info", "g16_plonk_destroy", "g16_plonk_setup"]
+           "g16_plonk_create", "g16_plonk_prove", "g16_plonk_get_info", "g16_plonk_destroy", "g16_plonk_setup", "g16_plonk_timings"]
 
 
 def load():
@@ -130,6 +130,7 @@ def load():
     lib.g16_plonk_get_info.argtypes = [vp, C.POINTER(C.c_uint32)]
     lib.g16_plonk_destroy.argtypes = [vp]
     lib.g16_plonk_destroy.restype = None
+    lib.g16_plonk_timings.argtypes = [vp, C.POINTER(C.c_float)]
     lib.g16_plonk_setup.argtypes = [C.c_char_p, sz, C.c_uint64, C.c_int, C.c_int, C.POINTER(vp), C.POINTER(sz)]
     lib.g16_r1cs_setup.argtypes = [C.c_char_p, sz, C.c_uint64, C.c_int, C.POINTER(vp), C.POINTER(sz), C.POINTER(vp), C.POINTER(sz)]
     lib.g16_sha256_chain_setup.argtypes = [C.c_uint32, C.c_char_p, C.c_uint64, C.c_int] + [C.c_void_p] * 8
@@ -624,6 +625,11 @@ class PlonkProver:
             blinding = b"".join(int(x).to_bytes(32, "little") for x in blinding)
         pr, pub = self.prove_raw(wtns, blinding)
         return plonk_proof_to_obj(pr), [_dec(pub[i * 32:(i + 1) * 32]) for i in range(self.n_public)]
+
+    def timings(self):
+        ms = (C.c_float * 6)()
+        _check(load().g16_plonk_timings(self._h, ms))
+        return dict(zip(("witness_round1", "round2", "round3", "round4", "round5", "total"), [round(x, 3) for x in ms]))
 
     def close(self):
         if getattr(self, "_h", None) and self._h.value:

@@ -26,6 +26,7 @@
 #include <unistd.h>
 
 #include <algorithm>
+#include <chrono>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -748,6 +749,13 @@ int plonk_prove_impl(g16_plonk* P, const uint8_t* wtns, size_t wlen, const uint8
   hipStream_t st = P->st;
   const uint32_t N = P->N;
   const size_t n4 = (size_t)N * 4;
+  auto tprev = std::chrono::steady_clock::now();
+  const auto tstart = tprev;
+  auto lap = [&](int k) {   // host wall time of a round (each ends in a commitment, which waits for the device)
+    const auto now = std::chrono::steady_clock::now();
+    P->last_ms[k] = std::chrono::duration<float, std::milli>(now - tprev).count();
+    tprev = now;
+  };
   // ---- witness: first element zeroed ("not used in plonk"), additions level by level, A/B/C
   G16_HIP(hipMemcpyAsync(P->d_wraw, s[2].p, (size_t)P->nBase * 32, hipMemcpyHostToDevice, st));
   k_to_mont<<<nblk(P->nBase), 256, 0, st>>>(P->d_wraw, P->d_w, P->nBase, 1u);
@@ -776,6 +784,7 @@ int plonk_prove_impl(g16_plonk* P, const uint8_t* wtns, size_t wlen, const uint8
   if ((rc = commit(P, P->d_pa, N + 2, &pr->A))) return rc;
   if ((rc = commit(P, P->d_pb, N + 2, &pr->B))) return rc;
   if ((rc = commit(P, P->d_pc, N + 2, &pr->C))) return rc;
+  lap(0);
   // ---- round 2
   std::vector<uint8_t> tr;
   put_g1_be(tr, pr->A);
@@ -809,6 +818,7 @@ int plonk_prove_impl(g16_plonk* P, const uint8_t* wtns, size_t wlen, const uint8
   Pz pzz{{b[9], b[8], b[7]}, 3};
   if ((rc = to4t(P->d_Z, pzz, P->d_pz, P->d_Z4))) return rc;
   if ((rc = commit(P, P->d_pz, N + 3, &pr->Z))) return rc;
+  lap(1);
   // ---- round 3
   tr.clear();
   put_g1_be(tr, pr->Z);
@@ -845,6 +855,7 @@ int plonk_prove_impl(g16_plonk* P, const uint8_t* wtns, size_t wlen, const uint8
   if ((rc = commit(P, P->d_T, N, &pr->T1))) return rc;
   if ((rc = commit(P, P->d_T + N, N, &pr->T2))) return rc;
   if ((rc = commit(P, P->d_T + 2 * (size_t)N, N + 6, &pr->T3))) return rc;
+  lap(2);
   // ---- round 4
   tr.clear();
   put_g1_be(tr, pr->T1);
@@ -878,6 +889,7 @@ int plonk_prove_impl(g16_plonk* P, const uint8_t* wtns, size_t wlen, const uint8
     G16_HIP(hipGetLastError());
   }
   if ((rc = eval_pol(P, P->d_r, N + 3, xi, &pr->er))) return rc;
+  lap(3);
   // ---- round 5
   tr.clear();
   put_fr_be(tr, pr->ea); put_fr_be(tr, pr->eb); put_fr_be(tr, pr->ec); put_fr_be(tr, pr->es1); put_fr_be(tr, pr->es2);
@@ -899,6 +911,8 @@ int plonk_prove_impl(g16_plonk* P, const uint8_t* wtns, size_t wlen, const uint8
   k_sub0<<<1, 1, 0, st>>>(P->d_wxi, pr->ezw);
   if ((rc = div_pol1(P, P->d_wxi, N + 3, xiw, P->d_q))) return rc;
   if ((rc = commit(P, P->d_q, N + 3, &pr->Wxiw))) return rc;
+  lap(4);
+  P->last_ms[5] = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - tstart).count();
   return G16_OK;
 }
 
@@ -993,6 +1007,12 @@ extern "C" int g16_plonk_get_info(const g16_plonk* P, uint32_t info[6]) {
   if (!P || !info) { set_error("NULL argument"); return G16_E_ARG; }
   info[0] = P->nVars; info[1] = P->nPublic; info[2] = P->N; info[3] = P->nAdd; info[4] = P->nCons;
   info[5] = (uint32_t)(P->level_start.empty() ? 0 : P->level_start.size() - 1);
+  return G16_OK;
+}
+
+extern "C" int g16_plonk_timings(const g16_plonk* P, float ms[6]) {
+  if (!P || !ms) { set_error("NULL argument"); return G16_E_ARG; }
+  for (int k = 0; k < 6; k++) ms[k] = P->last_ms[k];
   return G16_OK;
 }
 

@@ -76,7 +76,7 @@ def main():
                       "config": {"workload": f"{a.circuit}: NZCPPubIdentity{tuple(params)} as PLONK, domain 2^{prover.domain_size.bit_length() - 1}, "
                                              f"{prover.n_constraints} gates ({prover.n_additions} addition gates), {prover.n_public} public signals"},
                       "data": "real NZCP constraint system built natively, test-only setup with a known tau",
-                      "verified_by_oracle": verified}))
+                      "rounds_ms": prover.timings(), "verified_by_oracle": verified}))
     prover.close()
 
 
