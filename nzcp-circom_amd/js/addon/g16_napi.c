@@ -16,6 +16,9 @@
  *           createVerifier(vkey: Buffer, nPublic, montgomery: 0|1, device) -> Promise<vhandle>   (g16_verifier_create)
  *           verifyBatch(vhandle, proofs: Buffer(count*256), pubs: Buffer(count*nPublic*32)) -> Promise<Buffer(count)>
  *           destroyVerifier(vhandle)
+ *           plonkCreate(zkey: Buffer, device) -> Promise<phandle>                                  (g16_plonk_create)
+ *           plonkProve(phandle, wtns: Buffer, blinding: Buffer(288)|null) -> Promise<{proof: Buffer(832), pub: Buffer}>
+ *           plonkDestroy(phandle)
  */
 #include <node_api.h>
 #include <stdlib.h>
@@ -495,6 +498,155 @@ static napi_value js_destroy_verifier(napi_env env, napi_callback_info info) {
   return NULL;
 }
 
+/* ------------------------------------------------------------------ PLONK prover (g16_plonk_*): snarkjs plonk.prove */
+typedef struct {
+  g16_plonk* p;
+  uint32_t n_public;
+  uint32_t inflight;
+  int closing;
+} phandle_t;
+
+static void phandle_finalize(napi_env env, void* data, void* hint) {
+  phandle_t* h = (phandle_t*)data;
+  if (h->p) g16_plonk_destroy(h->p);
+  free(h);
+}
+
+typedef struct {
+  napi_async_work work;
+  napi_deferred deferred;
+  napi_ref refs[3];
+  int nrefs;
+  int kind;                 /* 0 = create, 1 = prove */
+  const uint8_t* zkey; size_t zkey_len; int device; g16_plonk* created; uint32_t info[6];
+  phandle_t* h; const uint8_t* wtns; size_t wtns_len; int have_blind; uint8_t blind[288];
+  g16_plonk_proof proof; uint8_t* pub; size_t pub_len;
+  int rc; char err[512];
+} pjob_t;
+
+static void pjob_execute(napi_env env, void* data) {
+  pjob_t* j = (pjob_t*)data;
+  if (j->kind == 0) {
+    j->rc = g16_plonk_create(j->zkey, j->zkey_len, j->device, &j->created);
+    if (!j->rc) g16_plonk_get_info(j->created, j->info);
+  } else {
+    j->rc = g16_plonk_prove(j->h->p, j->wtns, j->wtns_len, j->have_blind ? j->blind : NULL, &j->proof, j->pub);
+  }
+  if (j->rc) {
+    strncpy(j->err, g16_last_error(), sizeof(j->err) - 1);
+    j->err[sizeof(j->err) - 1] = 0;
+  }
+}
+
+static void pjob_complete(napi_env env, napi_status status, void* data) {
+  pjob_t* j = (pjob_t*)data;
+  napi_value result;
+  if (status != napi_ok || j->rc) {
+    napi_value msg, err;
+    napi_create_string_utf8(env, j->rc ? j->err : "g16 addon: async work cancelled", NAPI_AUTO_LENGTH, &msg);
+    napi_create_error(env, NULL, msg, &err);
+    napi_reject_deferred(env, j->deferred, err);
+  } else if (j->kind == 0) {
+    phandle_t* h = (phandle_t*)calloc(1, sizeof(phandle_t));
+    h->p = j->created;
+    h->n_public = j->info[1];
+    napi_create_external(env, h, phandle_finalize, NULL, &result);
+    napi_resolve_deferred(env, j->deferred, result);
+  } else {
+    napi_value proof, pub;
+    void* dst;
+    napi_create_object(env, &result);
+    napi_create_buffer_copy(env, sizeof(g16_plonk_proof), &j->proof, &dst, &proof);
+    napi_create_buffer_copy(env, j->pub_len, j->pub, &dst, &pub);
+    napi_set_named_property(env, result, "proof", proof);
+    napi_set_named_property(env, result, "pub", pub);
+    napi_resolve_deferred(env, j->deferred, result);
+  }
+  if (j->h) {
+    j->h->inflight--;
+    if (j->h->closing && j->h->inflight == 0 && j->h->p) { g16_plonk_destroy(j->h->p); j->h->p = NULL; }
+  }
+  for (int i = 0; i < j->nrefs; i++) napi_delete_reference(env, j->refs[i]);
+  napi_delete_async_work(env, j->work);
+  free(j->pub);
+  free(j);
+}
+
+static napi_value queue_pjob(napi_env env, pjob_t* j, const char* name) {
+  napi_value promise, resname;
+  NAPI_OK(napi_create_promise(env, &j->deferred, &promise));
+  NAPI_OK(napi_create_string_utf8(env, name, NAPI_AUTO_LENGTH, &resname));
+  NAPI_OK(napi_create_async_work(env, NULL, resname, pjob_execute, pjob_complete, j, &j->work));
+  NAPI_OK(napi_queue_async_work(env, j->work));
+  return promise;
+}
+
+static napi_value js_plonk_create(napi_env env, napi_callback_info info) {
+  size_t argc = 2;
+  napi_value argv[2];
+  bool isbuf = false;
+  NAPI_OK(napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
+  if (argc < 1 || napi_is_buffer(env, argv[0], &isbuf) != napi_ok || !isbuf) {
+    napi_throw_type_error(env, NULL, "plonkCreate(zkey: Buffer, device)");
+    return NULL;
+  }
+  pjob_t* j = (pjob_t*)calloc(1, sizeof(pjob_t));
+  void* data;
+  int32_t dev = 0;
+  NAPI_OK(napi_get_buffer_info(env, argv[0], &data, &j->zkey_len));
+  j->zkey = (const uint8_t*)data;
+  if (argc > 1) napi_get_value_int32(env, argv[1], &dev);
+  j->device = dev;
+  NAPI_OK(napi_create_reference(env, argv[0], 1, &j->refs[j->nrefs++]));
+  return queue_pjob(env, j, "g16_plonk_create");
+}
+
+static napi_value js_plonk_prove(napi_env env, napi_callback_info info) {
+  size_t argc = 3;
+  napi_value argv[3];
+  phandle_t* h = NULL;
+  bool isbuf = false;
+  NAPI_OK(napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
+  if (argc < 2 || napi_get_value_external(env, argv[0], (void**)&h) != napi_ok || !h || !h->p || h->closing ||
+      napi_is_buffer(env, argv[1], &isbuf) != napi_ok || !isbuf) {
+    napi_throw_type_error(env, NULL, "plonkProve(phandle, wtns: Buffer, blinding: Buffer|null)");
+    return NULL;
+  }
+  pjob_t* j = (pjob_t*)calloc(1, sizeof(pjob_t));
+  j->kind = 1;
+  j->h = h;
+  void* data;
+  NAPI_OK(napi_get_buffer_info(env, argv[1], &data, &j->wtns_len));
+  j->wtns = (const uint8_t*)data;
+  if (argc > 2) {
+    bool b = false;
+    size_t bl = 0;
+    void* bd;
+    if (napi_is_buffer(env, argv[2], &b) == napi_ok && b && napi_get_buffer_info(env, argv[2], &bd, &bl) == napi_ok && bl == 288) {
+      memcpy(j->blind, bd, 288);
+      j->have_blind = 1;
+    }
+  }
+  j->pub_len = (size_t)h->n_public * 32;
+  j->pub = (uint8_t*)calloc(j->pub_len ? j->pub_len : 1, 1);
+  h->inflight++;
+  NAPI_OK(napi_create_reference(env, argv[0], 1, &j->refs[j->nrefs++]));
+  NAPI_OK(napi_create_reference(env, argv[1], 1, &j->refs[j->nrefs++]));
+  return queue_pjob(env, j, "g16_plonk_prove");
+}
+
+static napi_value js_plonk_destroy(napi_env env, napi_callback_info info) {
+  size_t argc = 1;
+  napi_value argv[1];
+  phandle_t* h = NULL;
+  NAPI_OK(napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
+  if (argc >= 1 && napi_get_value_external(env, argv[0], (void**)&h) == napi_ok && h && h->p) {
+    h->closing = 1;
+    if (h->inflight == 0) { g16_plonk_destroy(h->p); h->p = NULL; }
+  }
+  return NULL;
+}
+
 static napi_value init(napi_env env, napi_value exports) {
   napi_property_descriptor props[] = {
       {"create", NULL, js_create, NULL, NULL, NULL, napi_default, NULL},
@@ -506,6 +658,9 @@ static napi_value init(napi_env env, napi_value exports) {
       {"createVerifier", NULL, js_create_verifier, NULL, NULL, NULL, napi_default, NULL},
       {"verifyBatch", NULL, js_verify_batch, NULL, NULL, NULL, napi_default, NULL},
       {"destroyVerifier", NULL, js_destroy_verifier, NULL, NULL, NULL, napi_default, NULL},
+      {"plonkCreate", NULL, js_plonk_create, NULL, NULL, NULL, napi_default, NULL},
+      {"plonkProve", NULL, js_plonk_prove, NULL, NULL, NULL, napi_default, NULL},
+      {"plonkDestroy", NULL, js_plonk_destroy, NULL, NULL, NULL, napi_default, NULL},
   };
   NAPI_OK(napi_define_properties(env, exports, sizeof(props) / sizeof(props[0]), props));
   return exports;

@@ -10,6 +10,14 @@ const { groth16 } = require("./index.js");
 
 async function main(argv) {
   let a = argv.slice(2);
+  if (a[0] === "plonk" && a[1] === "prove") {   // snarkjs plonk prove <circuit.zkey> <witness.wtns> [proof.json] [public.json]
+    const [zk, wt, proofFile = "proof.json", publicFile = "public.json"] = a.slice(2).filter((x) => !x.startsWith("--"));
+    const { plonk } = require("./index.js");
+    const { proof, publicSignals } = await plonk.prove(zk, wt);
+    fs.writeFileSync(proofFile, JSON.stringify(proof, null, 1), "utf-8");
+    fs.writeFileSync(publicFile, JSON.stringify(publicSignals, null, 1), "utf-8");
+    return;
+  }
   if (a[0] === "groth16") a = a.slice(1);
   if (a[0] === "verify") {
     const pos = a.slice(1).filter((x) => !x.startsWith("--"));

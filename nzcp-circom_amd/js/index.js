@@ -168,6 +168,61 @@ async function createVerifier(vk, opts = {}) {
   return new Verifier(h, Number(vk.nPublic));
 }
 
+// ------------------------------------------------------------------ PLONK (snarkjs plonk.prove on the GPU, csrc/plonk.hip)
+const PLONK_G1 = ["A", "B", "C", "Z", "T1", "T2", "T3"];
+const PLONK_EV = ["eval_a", "eval_b", "eval_c", "eval_s1", "eval_s2", "eval_zw", "eval_r"];
+// g16_plonk_proof bytes -> the object snarkjs's plonk_prove.js stringifies (its key order)
+function plonkProofObject(raw) {
+  const g1 = (o) => (isZero(raw, o, 64) ? ["0", "1", "0"] : [dec(raw, o), dec(raw, o + 32), "1"]);
+  const out = {};
+  let o = 0;
+  for (const k of PLONK_G1) { out[k] = g1(o); o += 64; }
+  for (const k of PLONK_EV) { out[k] = dec(raw, o); o += 32; }
+  out.Wxi = g1(o); out.Wxiw = g1(o + 64);
+  out.protocol = "plonk"; out.curve = "bn128";
+  return out;
+}
+class PlonkProver {
+  constructor(handle) { this._h = handle; this._busy = Promise.resolve(); }
+  // opts.blinding: nine scalars b1..b9 (decimal strings / BigInts) for a reproducible proof; default: fresh randomness
+  prove(wtns, opts = {}) {
+    if (!this._h) return Promise.reject(new Error("prover is closed"));
+    const w = toBuffer(wtns, "wtns"), h = this._h;
+    let bl = null;
+    if (opts.blinding) {
+      if (opts.blinding.length !== 9) return Promise.reject(new Error("blinding: nine scalars b1..b9 expected"));
+      bl = Buffer.concat(opts.blinding.map(scalarToBuffer));
+    }
+    const run = () => native().plonkProve(h, w, bl)
+      .then(({ proof, pub }) => ({ proof: plonkProofObject(proof), publicSignals: publicSignals(pub) }));
+    const p = this._busy.then(run, run);
+    this._busy = p.catch(() => {});
+    return p;
+  }
+  close() {
+    if (!this._h) return this._busy;
+    const h = this._h;
+    this._h = null;
+    this._busy = this._busy.then(() => native().plonkDestroy(h));
+    return this._busy;
+  }
+}
+const plonk = {
+  // snarkjs: plonk.prove(zkeyFileName, witnessFileName[, logger]) -> {proof, publicSignals}
+  async prove(zkey, wtns, opts = {}) {
+    if (opts && typeof opts.debug === "function") opts = {};
+    const prover = await plonk.createProver(zkey, opts);
+    try {
+      return await prover.prove(wtns, opts);
+    } finally {
+      await prover.close();
+    }
+  },
+  async createProver(zkey, opts = {}) {
+    return new PlonkProver(await native().plonkCreate(toBuffer(zkey, "zkey"), opts.device | 0));
+  },
+};
+
 const groth16 = {
   // snarkjs: groth16.verify(vk_verifier, publicSignals, proof[, logger]) -> boolean
   async verify(vk, publicSignals, proof, opts = {}) {
@@ -192,4 +247,4 @@ const groth16 = {
   createProver,
 };
 
-module.exports = { groth16, createProver, Prover, createVerifier, Verifier, proofObject, publicSignals, proofBytes, vkeyBytes };
+module.exports = { groth16, plonk, PlonkProver, plonkProofObject, createProver, Prover, createVerifier, Verifier, proofObject, publicSignals, proofBytes, vkeyBytes };

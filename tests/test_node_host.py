@@ -119,6 +119,49 @@ def test_node_verify_and_cli(addon, tmp_path):
 
 @needs_node
 @pytest.mark.gpu
+def test_node_plonk_prove(addon, tmp_path):
+    """snarkjs `plonk.prove(zkey, wtns)` through the Node host: with the oracle's blinding the proof object is the
+    oracle's (oracle/plonk.py), with fresh randomness it still passes the oracle's KZG verifier; the CLI twin writes
+    proof.json / public.json."""
+    import plonk as pk
+    import synth
+    n, p, m, seed = 60, 5, 40, 3
+    rows, w = synth.make(n, p, m, seed)
+    zk = pk.setup(n, p, rows, tau=31337)
+    zf, wf = tmp_path / "c.zkey", tmp_path / "w.wtns"
+    zf.write_bytes(pk.write_zkey(zk))
+    wf.write_bytes(f.write_wtns(w))
+    rng = synth.Xoshiro(77)
+    bl = {i: rng.rand_fr() for i in range(1, 10)}
+    script = f"""
+    const {{ plonk }} = require({json.dumps(JS)});
+    (async () => {{
+      const a = await plonk.prove({json.dumps(str(zf))}, {json.dumps(str(wf))}, {{blinding: {json.dumps([str(bl[i]) for i in range(1, 10)])}}});
+      const b = await plonk.prove({json.dumps(str(zf))}, {json.dumps(str(wf))});
+      let err = "none";
+      try {{ await plonk.prove({json.dumps(golden_path('tiny.zkey'))}, {json.dumps(str(wf))}); }} catch (e) {{ err = e.message; }}
+      console.log(JSON.stringify({{a, b, err}}));
+    }})();
+    """
+    r = run_node(script)
+    assert r.returncode == 0, r.stderr
+    out = json.loads(r.stdout)
+    exp, exp_pub = pk.prove(zk, w, bl)
+    assert out["a"]["proof"] == pk.proof_obj(exp) and out["a"]["publicSignals"] == [str(x) for x in exp_pub]
+    assert list(out["a"]["proof"].keys()) == ["A", "B", "C", "Z", "T1", "T2", "T3", "eval_a", "eval_b", "eval_c", "eval_s1",
+                                              "eval_s2", "eval_zw", "eval_r", "Wxi", "Wxiw", "protocol", "curve"]
+    assert out["b"]["proof"]["A"] != out["a"]["proof"]["A"]
+    assert pk.verify(pk.vkey(zk), [int(x) for x in out["b"]["publicSignals"]], pk.proof_from_obj(out["b"]["proof"]))
+    assert out["err"] == "zkey file is not plonk"
+    pj, uj = tmp_path / "proof.json", tmp_path / "public.json"
+    r = subprocess.run(["node", os.path.join(JS, "cli.js"), "plonk", "prove", str(zf), str(wf), str(pj), str(uj)],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    assert pk.verify(pk.vkey(zk), [int(x) for x in json.loads(uj.read_text())], pk.proof_from_obj(json.loads(pj.read_text())))
+
+
+@needs_node
+@pytest.mark.gpu
 def test_resident_prover_and_random_blinding(addon):
     meta = json.load(open(golden_path("small.json")))
     script = f"""
