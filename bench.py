@@ -213,6 +213,41 @@ def verify_leg(amd, args, vkey, proofs, pubs, dev, log):
             "mode": "g16_verify_batch: host buffers in, one verdict per proof out (uploads inside the timed region)"}
 
 
+def plonk_leg(amd, dev, log, steps=3):
+    """the PLONK prover (csrc/plonk.hip) on nzcp_exampleTest as PLONK -- the circuit whose PLONK setup
+    the reference scripts (Makefile:30-33).  Key from the test-only setup with a known tau; fresh random blinding per
+    proof; the last proof is checked by the oracle's KZG verifier.  An extra figure, never `value`."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    entry.oracle_path()
+    import nzcp_pass
+    import plonk as pk
+    t0 = time.time()
+    params = amd.NZCP_EXAMPLE_PARAMS
+    out = amd.nzcp_circuit_setup(params, nzcp_pass.to_be_signed("Jack", "Sparrow", "1960-04-16", live=False, exp=1951416330),
+                                 SEED, 0, want_zkey=False, want_r1cs=True)
+    zkey = amd.plonk_setup(out["r1cs"], SEED, device=dev, with_lagrange=False)
+    vk = pk.vkey_from_zkey(zkey)
+    prover = amd.PlonkProver(zkey, device=dev)
+    del zkey
+    prover.prove_raw(out["wtns"])
+    ts = []
+    for _ in range(steps):
+        t = time.perf_counter()
+        prover.prove_raw(out["wtns"])
+        ts.append(time.perf_counter() - t)
+    rounds = prover.timings()
+    proof, pub = prover.prove(out["wtns"])
+    ok = pk.verify(vk, [int(x) for x in pub], pk.proof_from_obj(proof))
+    res = {"proofs_per_sec": round(1 / min(ts), 3), "ms_per_proof": round(min(ts) * 1e3, 2),
+           "workload": f"nzcp_exampleTest as PLONK: domain 2^{prover.domain_size.bit_length() - 1}, {prover.n_constraints} gates, "
+                       f"{prover.n_additions} addition gates, {prover.n_public} public signals",
+           "rounds_ms": rounds, "verified_by_oracle_kzg": bool(ok), "prepare_s": round(time.time() - t0, 1)}
+    prover.close()
+    log(f"plonk: {res['ms_per_proof']} ms per proof, verified {ok}")
+    assert ok, "PLONK proof rejected by the oracle verifier"
+    return res
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -240,6 +275,7 @@ def main():
     ap.add_argument("--batch-proofs", type=int, default=1024,
                     help="proofs in the throughput leg: BASELINE config 3 is stated on 1 024 independent witnesses "
                          "(8 distinct ones cycled; every proof is compared with its one-by-one result)")
+    ap.add_argument("--no-plonk", action="store_true", help="skip the PLONK prover leg (extra figure at N=1)")
     args = ap.parse_args()
 
     args.nz = None
@@ -544,6 +580,12 @@ def main():
             out["batch_verify"] = verify
         if replicas is not None:
             out["replicas_throughput"] = replicas
+        if world == 1 and not args.no_plonk and not args.no_cpu:
+            prover.close()
+            try:
+                out["plonk_prover"] = plonk_leg(amd, dev, log)
+            except Exception as e:  # noqa: BLE001  (an extra leg must not cost the headline line)
+                out["plonk_prover"] = {"error": repr(e)[:300]}
         if world == 1 and not args.no_cpu:
             gpu_bytes = bytes(pr.a) + bytes(pr.b) + bytes(pr.c)
             prover.close()

@@ -73,3 +73,24 @@ def test_setup_tool_equals_oracle(amd, n, p, m, seed, lag):
     proof, pub = prover.prove(f.write_wtns(w))
     prover.close()
     assert pk.verify(pk.vkey(zk), [int(x) for x in pub], pk.proof_from_obj(proof))
+
+
+def test_full_size_nzcp_example_as_plonk(amd):
+    """The circuit whose PLONK setup the reference scripts (/root/reference/Makefile:30-33), at full size: natively built
+    nzcp_exampleTest -> 2.59 M gates, domain 2^22 -> device setup (known tau), device proof, accepted by the oracle's
+    KZG verifier; its public signals are the reference's 513 golden values of the example pass."""
+    from test_cpu_sha256_circuit import example_public_signals, example_to_be_signed
+    tbs = example_to_be_signed()
+    out = amd.nzcp_circuit_setup(amd.NZCP_EXAMPLE_PARAMS, tbs, 7, 0, want_zkey=False, want_r1cs=True)
+    zkey = amd.plonk_setup(out["r1cs"], 7, device=0, with_lagrange=False)
+    vk = pk.vkey_from_zkey(zkey)
+    prover = amd.PlonkProver(zkey, device=0)
+    del zkey
+    assert prover.domain_size == 1 << 22 and prover.n_public == 513
+    proof, pub = prover.prove(out["wtns"])
+    prover.close()
+    assert pub == [str(x) for x in example_public_signals()]       # /root/reference/test/nzcp.js:41-49
+    assert pk.verify(vk, [int(x) for x in pub], pk.proof_from_obj(proof))
+    bad = list(pub)
+    bad[100] = str(1 - int(bad[100]))
+    assert not pk.verify(vk, [int(x) for x in bad], pk.proof_from_obj(proof))
