@@ -20,7 +20,7 @@ G16_TRACE_HOST=1 timeout -k 10 200 python bench.py --steps 8 --warmup 3 --no-cpu
 G16_SERIAL_MSM=1 G16_TRACE_HOST=1 timeout -k 10 200 python bench.py --steps 8 --warmup 3 --no-cpu --batch-streams 0 > /dev/null 2> $OUT/trace_serial.err
 ( echo "# device timeline, default bench workload, averaged over 5 proofs (tools/trace_phases.py on G16_TRACE_HOST=1 output): phase durations in ms"; echo "# concurrent (product schedule):"; python tools/trace_phases.py $OUT/trace_conc.err 3; echo "# everything on one stream (G16_SERIAL_MSM=1): standalone stage durations (the G2 lane's dup-row stage still overlaps its reduce)"; python tools/trace_phases.py $OUT/trace_serial.err 3 ) > $OUT/device_timeline.txt
 # the 1.7 M upper-estimate synthetic circuit (round 1's workload) and the example circuit, for continuity
-timeout -k 10 400 python bench.py --circuit synthetic --steps 30 --warmup 5 --batch-proofs 256 > $OUT/bench_synthetic.json 2> $OUT/bench_synthetic.err
+timeout -k 10 400 python bench.py --circuit synthetic --steps 30 --warmup 5 --batch-proofs 256 --no-plonk > $OUT/bench_synthetic.json 2> $OUT/bench_synthetic.err
 timeout -k 10 400 python bench.py --circuit nzcp_example --steps 30 --warmup 5 --batch-proofs 256 --no-cpu > $OUT/bench_example.json 2> $OUT/bench_example.err
 find $OUT -name "*.csv" | head -20
 tail -c 600 $OUT/bench.json
