@@ -31,6 +31,7 @@
 #include <string>
 #include <vector>
 
+#include "fr29.cuh"
 #include "internal.h"
 
 namespace g16 {
@@ -238,29 +239,41 @@ __global__ __launch_bounds__(256) void k_z_apply(const FrM* __restrict__ lp, con
   if (i + 1 < n) Z[i + 1] = fp_mul(carry[i / kChunk], lp[i]);
 }
 
+// Round 3 runs on the 9 x 29-bit lazy Montgomery field of the NTT kernels (fr29.cuh: 241 instructions per product
+// against ~530 of the canonical 8x32 product): its inputs are the 4N-point transforms left in the lazy format (no
+// export), its outputs go straight into the inverse transforms' working vectors (no import).  Discipline: every sum and
+// difference is weak-reduced (< 1.0001 r), so every product input is < 2.5 r and every subtrahend < 3 r.
+using L9 = F29;
+__device__ __forceinline__ L9 lmul(const L9& a, const L9& b) { return fr29_mul(a, b); }
+__device__ __forceinline__ L9 ladd(const L9& a, const L9& b) { return fr29_weak_reduce(fr29_add(a, b)); }
+__device__ __forceinline__ L9 lsub(const L9& a, const L9& b) { return fr29_weak_reduce(fr29_sub<3>(a, b)); }
+__global__ __launch_bounds__(256) void k_to_lazy(const FrM* __restrict__ in, L9* __restrict__ out, size_t n) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  out[i] = fr29_from_fr(in[i]);
+}
 struct R3Args {
-  FrM beta, gamma, alpha, alpha2, k1, k2, w1;
-  FrM b[10];
-  FrM Z1[4], Z2[4], Z3[4];
+  L9 beta, gamma, alpha, alpha2, k1, k2, w1, one;
+  L9 b[10];
+  L9 Z1[4], Z2[4], Z3[4];
 };
 struct R3Ptrs {
-  const FrM *A4, *B4, *C4, *Z4, *qm, *ql, *qr, *qo, *qc, *s1, *s2, *s3, *pi4, *l1, *om4;
+  const L9 *A4, *B4, *C4, *Z4, *qm, *ql, *qr, *qo, *qc, *s1, *s2, *s3, *pi4, *l1, *om4;
 };
-// (c0 + c1 t)(x + xp t) style accumulation of the blinded factors: the coefficients of t^k of prod (x_k + xp_k t)
-__device__ __forceinline__ void poly_mul_lin(FrM* c, int deg, const FrM& x, const FrM& xp) {
-  // c has deg + 1 coefficients; result deg + 2
-  FrM carry = fp_zero<FrParams>();
+// the coefficients of t^k of prod (x_k + xp_k t), one linear factor at a time
+__device__ __forceinline__ void poly_mul_lin(L9* c, int deg, const L9& x, const L9& xp) {
+  L9 carry = f29_zero();
   for (int k = 0; k <= deg; k++) {
-    const FrM lo = fp_mul(c[k], x);
-    const FrM hi = fp_mul(c[k], xp);
-    c[k] = fp_add(lo, carry);
+    const L9 lo = lmul(c[k], x);
+    const L9 hi = lmul(c[k], xp);
+    c[k] = k ? ladd(lo, carry) : lo;
     carry = hi;
   }
   c[deg + 1] = carry;
 }
-__device__ __forceinline__ void mul4z(const FrM& x, const FrM& y, const FrM& u, const FrM& v, const FrM& xp, const FrM& yp,
-                                      const FrM& up, const FrM& vp, uint32_t p, const R3Args& a, FrM& r, FrM& rz) {
-  FrM c[5];
+__device__ __forceinline__ void mul4z(const L9& x, const L9& y, const L9& u, const L9& v, const L9& xp, const L9& yp,
+                                      const L9& up, const L9& vp, uint32_t p, const R3Args& a, L9& r, L9& rz) {
+  L9 c[5];
   c[0] = x;
   c[1] = xp;
   poly_mul_lin(c, 1, y, yp);
@@ -268,41 +281,44 @@ __device__ __forceinline__ void mul4z(const FrM& x, const FrM& y, const FrM& u, 
   poly_mul_lin(c, 3, v, vp);
   r = c[0];
   rz = c[1];
-  if (p) rz = fp_add(rz, fp_add(fp_mul(a.Z1[p], c[2]), fp_add(fp_mul(a.Z2[p], c[3]), fp_mul(a.Z3[p], c[4]))));
+  if (p) rz = ladd(rz, ladd(lmul(a.Z1[p], c[2]), ladd(lmul(a.Z2[p], c[3]), lmul(a.Z3[p], c[4]))));
 }
-__global__ __launch_bounds__(256) void k_round3(R3Ptrs q, R3Args a, uint32_t n4, FrM* __restrict__ T, FrM* __restrict__ Tz) {
+__global__ __launch_bounds__(256) void k_round3(R3Ptrs q, R3Args a, uint32_t n4, L9* __restrict__ T, L9* __restrict__ Tz) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n4) return;
   const uint32_t p = i & 3u;
-  const FrM w = q.om4[i];
-  const FrM A = q.A4[i], B = q.B4[i], C = q.C4[i], Z = q.Z4[i], ZW = q.Z4[(i + 4) % n4];
-  const FrM ap = fp_add(a.b[2], fp_mul(a.b[1], w));
-  const FrM bp = fp_add(a.b[4], fp_mul(a.b[3], w));
-  const FrM cp = fp_add(a.b[6], fp_mul(a.b[5], w));
-  const FrM w2 = fp_sqr(w);
-  const FrM zp = fp_add(fp_add(fp_mul(a.b[7], w2), fp_mul(a.b[8], w)), a.b[9]);
-  const FrM ww = fp_mul(w, a.w1);
-  const FrM zwp = fp_add(fp_add(fp_mul(a.b[7], fp_sqr(ww)), fp_mul(a.b[8], ww)), a.b[9]);
+  const L9 w = q.om4[i];
+  // (transform outputs may sit anywhere below 16 r: reduce on load)
+  const L9 A = fr29_weak_reduce(q.A4[i]), B = fr29_weak_reduce(q.B4[i]), C = fr29_weak_reduce(q.C4[i]);
+  const L9 Z = fr29_weak_reduce(q.Z4[i]), ZW = fr29_weak_reduce(q.Z4[(i + 4) % n4]);
+  const L9 ap = ladd(a.b[2], lmul(a.b[1], w));
+  const L9 bp = ladd(a.b[4], lmul(a.b[3], w));
+  const L9 cp = ladd(a.b[6], lmul(a.b[5], w));
+  const L9 w2 = lmul(w, w);
+  const L9 zp = ladd(ladd(lmul(a.b[7], w2), lmul(a.b[8], w)), a.b[9]);
+  const L9 ww = lmul(w, a.w1);
+  const L9 zwp = ladd(ladd(lmul(a.b[7], lmul(ww, ww)), lmul(a.b[8], ww)), a.b[9]);
   // gate
-  const FrM qm = q.qm[i], ql = q.ql[i], qr = q.qr[i], qo = q.qo[i];
-  FrM e1 = fp_mul(fp_mul(A, B), qm);
-  FrM e1z = fp_add(fp_mul(A, bp), fp_mul(ap, B));
-  if (p) e1z = fp_add(e1z, fp_mul(a.Z1[p], fp_mul(ap, bp)));
-  e1z = fp_mul(e1z, qm);
-  e1 = fp_add(e1, fp_add(fp_add(fp_mul(A, ql), fp_mul(B, qr)), fp_add(fp_mul(C, qo), fp_add(q.pi4[i], q.qc[i]))));
-  e1z = fp_add(e1z, fp_add(fp_add(fp_mul(ap, ql), fp_mul(bp, qr)), fp_mul(cp, qo)));
+  const L9 qm = q.qm[i], ql = q.ql[i], qr = q.qr[i], qo = q.qo[i];
+  L9 e1 = lmul(lmul(A, B), qm);
+  L9 e1z = ladd(lmul(A, bp), lmul(ap, B));
+  if (p) e1z = ladd(e1z, lmul(a.Z1[p], lmul(ap, bp)));
+  e1z = lmul(e1z, qm);
+  const L9 pi = fr29_weak_reduce(q.pi4[i]);
+  e1 = ladd(e1, ladd(ladd(lmul(A, ql), lmul(B, qr)), ladd(lmul(C, qo), ladd(pi, q.qc[i]))));
+  e1z = ladd(e1z, ladd(ladd(lmul(ap, ql), lmul(bp, qr)), lmul(cp, qo)));
   // permutation
-  const FrM bw = fp_mul(a.beta, w);
-  FrM e2, e2z, e3, e3z;
-  mul4z(fp_add(fp_add(A, bw), a.gamma), fp_add(fp_add(B, fp_mul(bw, a.k1)), a.gamma), fp_add(fp_add(C, fp_mul(bw, a.k2)), a.gamma), Z,
-        ap, bp, cp, zp, p, a, e2, e2z);
-  mul4z(fp_add(fp_add(A, fp_mul(a.beta, q.s1[i])), a.gamma), fp_add(fp_add(B, fp_mul(a.beta, q.s2[i])), a.gamma),
-        fp_add(fp_add(C, fp_mul(a.beta, q.s3[i])), a.gamma), ZW, ap, bp, cp, zwp, p, a, e3, e3z);
-  const FrM l1 = q.l1[i];
-  const FrM e4 = fp_mul(fp_mul(fp_sub(Z, fp_one<FrParams>()), l1), a.alpha2);
-  const FrM e4z = fp_mul(fp_mul(zp, l1), a.alpha2);
-  T[i] = fp_add(fp_add(e1, fp_mul(a.alpha, fp_sub(e2, e3))), e4);
-  Tz[i] = fp_add(fp_add(e1z, fp_mul(a.alpha, fp_sub(e2z, e3z))), e4z);
+  const L9 bw = lmul(a.beta, w);
+  L9 e2, e2z, e3, e3z;
+  mul4z(ladd(ladd(A, bw), a.gamma), ladd(ladd(B, lmul(bw, a.k1)), a.gamma), ladd(ladd(C, lmul(bw, a.k2)), a.gamma), Z, ap, bp, cp,
+        zp, p, a, e2, e2z);
+  mul4z(ladd(ladd(A, lmul(a.beta, q.s1[i])), a.gamma), ladd(ladd(B, lmul(a.beta, q.s2[i])), a.gamma),
+        ladd(ladd(C, lmul(a.beta, q.s3[i])), a.gamma), ZW, ap, bp, cp, zwp, p, a, e3, e3z);
+  const L9 l1 = fr29_weak_reduce(q.l1[i]);
+  const L9 e4 = lmul(lmul(lsub(Z, a.one), l1), a.alpha2);
+  const L9 e4z = lmul(lmul(zp, l1), a.alpha2);
+  T[i] = ladd(ladd(e1, lmul(a.alpha, lsub(e2, e3))), e4);
+  Tz[i] = ladd(ladd(e1z, lmul(a.alpha, lsub(e2z, e3z))), e4z);
 }
 // t = numerator / (X^n - 1) on 4n coefficients, in place: q_j = -p_j, q_{j+kn} = q_{j+(k-1)n} - p_{j+kn}; bad[0] is set
 // when a coefficient above 3n - 4 of the quotient is not zero.  Then t += tz below 3n + 6 (bad[1]: tz not zero above).
@@ -408,13 +424,14 @@ struct g16_plonk {
   FrM k1, k2, w1;
   hipStream_t st = nullptr;
   NttTables ntt_n, ntt_4n;
-  FrM* d_ext[8] = {};     // Qm Ql Qr Qo Qc S1 S2 S3, 4N evaluations
+  FrM* d_ext[8] = {};     // S1 S2 S3 (entries 5..7), 4N evaluations, canonical: round 2 reads them at the N-domain points
+  F29* d_ext_l[8] = {};   // Qm Ql Qr Qo Qc S1 S2 S3, 4N evaluations in the lazy format: round 3
   FrM* d_pol[8] = {};     // ... N coefficients
   uint32_t* d_map[3] = {};
   uint32_t *d_add_s1 = nullptr, *d_add_s2 = nullptr, *d_add_order = nullptr;
   FrM *d_add_f1 = nullptr, *d_add_f2 = nullptr;
   std::vector<uint32_t> level_start;
-  FrM *d_om4 = nullptr, *d_l1 = nullptr;
+  F29 *d_om4 = nullptr, *d_l1 = nullptr;   // w_4N^i and L1 on the 4N domain, lazy format
   MsmGroup srs;
   MsmWorkspace* ws = nullptr;
   // per-proof scratch
@@ -422,11 +439,12 @@ struct g16_plonk {
   FrM* d_w = nullptr;                   // extended witness, Montgomery
   FrM *d_A = nullptr, *d_B = nullptr, *d_C = nullptr, *d_Z = nullptr;   // N evaluations
   FrM *d_pa = nullptr, *d_pb = nullptr, *d_pc = nullptr, *d_pz = nullptr;   // blinded coefficient forms (N + 3)
-  FrM *d_A4 = nullptr, *d_B4 = nullptr, *d_C4 = nullptr, *d_Z4 = nullptr, *d_T = nullptr, *d_Tz = nullptr, *d_pi4 = nullptr;
+  F29 *d_A4 = nullptr, *d_B4 = nullptr, *d_C4 = nullptr, *d_Z4 = nullptr, *d_pi4 = nullptr;   // 4N evaluations, lazy format
+  FrM *d_T = nullptr, *d_Tz = nullptr;  // 4N canonical words: padding scratch, then the quotient's coefficients
   FrM *d_tmpN = nullptr, *d_tmpN2 = nullptr, *d_tmpN3 = nullptr, *d_tmpN4 = nullptr;   // N-sized scratch
   FrM *d_r = nullptr, *d_wxi = nullptr, *d_q = nullptr;
   FrM *d_tot = nullptr;                 // chunk totals / Horner partials
-  F29* d_lazy = nullptr;                // 4N lazy elements: the transforms' working vector
+  F29 *d_lazy = nullptr, *d_lazy2 = nullptr;   // 4N lazy elements each: the transforms' working vectors (T and Tz in round 3)
   Fr* d_scal = nullptr;                 // N + 6 standard-form MSM scalars
   uint32_t* d_bad = nullptr;
   std::vector<FrM> h_tot;
@@ -435,10 +453,11 @@ struct g16_plonk {
   ~g16_plonk() {
     (void)hipSetDevice(device);
     for (auto p : d_ext) if (p) (void)hipFree(p);
+    for (auto p : d_ext_l) if (p) (void)hipFree(p);
     for (auto p : d_pol) if (p) (void)hipFree(p);
     for (auto p : d_map) if (p) (void)hipFree(p);
     void* v[] = {d_add_s1, d_add_s2, d_add_order, d_add_f1, d_add_f2, d_om4, d_l1, d_wraw, d_w, d_A, d_B, d_C, d_Z, d_pa, d_pb, d_pc,
-                 d_pz, d_A4, d_B4, d_C4, d_Z4, d_T, d_Tz, d_pi4, d_tmpN, d_tmpN2, d_tmpN3, d_tmpN4, d_r, d_wxi, d_q, d_tot, d_lazy,
+                 d_pz, d_A4, d_B4, d_C4, d_Z4, d_T, d_Tz, d_pi4, d_tmpN, d_tmpN2, d_tmpN3, d_tmpN4, d_r, d_wxi, d_q, d_tot, d_lazy, d_lazy2,
                  d_scal, d_bad};
     for (void* p : v) if (p) (void)hipFree(p);
     if (ws) msm_workspace_destroy(ws);
@@ -486,6 +505,21 @@ int do_fft(const NttTables& t, const FrM* in, FrM* out, F29* lazy, hipStream_t s
   F29* v[1] = {lazy};
   if (!rc) rc = ntt_dit_forward(t, v, 1, st);
   if (!rc) rc = ntt_export(t, lazy, out, false, false, st);
+  return rc;
+}
+
+// 4N-point forward transform of canonical coefficients, the evaluations LEFT in the lazy format (natural order)
+int fft_to_lazy(const NttTables& t, const FrM* in, F29* out, hipStream_t st) {
+  int rc = ntt_import(t, in, out, true, st);
+  F29* v[1] = {out};
+  if (!rc) rc = ntt_dit_forward(t, v, 1, st);
+  return rc;
+}
+// inverse transform of a lazy vector in place, result exported as canonical coefficients
+int ifft_from_lazy(const NttTables& t, F29* inout, FrM* out, hipStream_t st) {
+  F29* v[1] = {inout};
+  int rc = ntt_dif_inverse(t, v, 1, st);
+  if (!rc) rc = ntt_export(t, inout, out, true, true, st);
   return rc;
 }
 
@@ -543,13 +577,24 @@ int plonk_create_impl(const uint8_t* zkey, size_t len, int device, g16_plonk* P)
   if ((rc = ntt_tables_create(P->ntt_n, (int)P->L, st))) return rc;
   if ((rc = ntt_tables_create(P->ntt_4n, (int)P->L + 2, st))) return rc;
   // polynomials: coefficients (N) then evaluations (4N)
+  FrM* d_stage = nullptr;   // the selectors' 4N evaluations pass through here on their way to the lazy format
+  G16_HIP(hipMalloc(&d_stage, (size_t)N * 128));
   for (int k = 0; k < 8; k++) {
     const uint8_t* src = k < 5 ? s[7 + k].p : s[12].p + (size_t)(k - 5) * polb;
     G16_HIP(hipMalloc(&P->d_pol[k], (size_t)N * 32));
-    G16_HIP(hipMalloc(&P->d_ext[k], (size_t)N * 128));
+    G16_HIP(hipMalloc(&P->d_ext_l[k], (size_t)N * 4 * sizeof(F29)));
+    FrM* dst = d_stage;
+    if (k >= 5) {   // sigma: round 2 reads the canonical evaluations at the N-domain points
+      G16_HIP(hipMalloc(&P->d_ext[k], (size_t)N * 128));
+      dst = P->d_ext[k];
+    }
     G16_HIP(hipMemcpyAsync(P->d_pol[k], src, (size_t)N * 32, hipMemcpyHostToDevice, st));
-    G16_HIP(hipMemcpyAsync(P->d_ext[k], src + (size_t)N * 32, (size_t)N * 128, hipMemcpyHostToDevice, st));
+    G16_HIP(hipMemcpyAsync(dst, src + (size_t)N * 32, (size_t)N * 128, hipMemcpyHostToDevice, st));
+    k_to_lazy<<<nblk((size_t)N * 4), 256, 0, st>>>(dst, P->d_ext_l[k], (size_t)N * 4);
+    G16_HIP(hipGetLastError());
   }
+  G16_HIP(hipStreamSynchronize(st));
+  (void)hipFree(d_stage);
   // maps, zero padded to N
   for (int c = 0; c < 3; c++) {
     G16_HIP(hipMalloc(&P->d_map[c], (size_t)N * 4));
@@ -599,28 +644,30 @@ int plonk_create_impl(const uint8_t* zkey, size_t len, int device, g16_plonk* P)
   }
   // scratch
   const size_t n4 = (size_t)N * 4;
-  FrM** four[] = {&P->d_A4, &P->d_B4, &P->d_C4, &P->d_Z4, &P->d_T, &P->d_Tz, &P->d_pi4, &P->d_om4, &P->d_l1};
+  FrM** four[] = {&P->d_T, &P->d_Tz};
   for (FrM** p : four) G16_HIP(hipMalloc(p, n4 * 32));
+  F29** four_l[] = {&P->d_A4, &P->d_B4, &P->d_C4, &P->d_Z4, &P->d_pi4, &P->d_om4, &P->d_l1, &P->d_lazy, &P->d_lazy2};
+  for (F29** p : four_l) G16_HIP(hipMalloc(p, n4 * sizeof(F29)));
   FrM** one[] = {&P->d_A, &P->d_B, &P->d_C, &P->d_Z, &P->d_tmpN, &P->d_tmpN2, &P->d_tmpN3, &P->d_tmpN4};
   for (FrM** p : one) G16_HIP(hipMalloc(p, (size_t)N * 32));
   FrM** plus[] = {&P->d_pa, &P->d_pb, &P->d_pc, &P->d_pz, &P->d_r, &P->d_wxi, &P->d_q};
   for (FrM** p : plus) G16_HIP(hipMalloc(p, ((size_t)N + 8) * 32));
   G16_HIP(hipMalloc(&P->d_wraw, (size_t)P->nBase * 32));
   G16_HIP(hipMalloc(&P->d_w, (size_t)P->nVars * 32));
-  G16_HIP(hipMalloc(&P->d_lazy, n4 * sizeof(F29)));
   G16_HIP(hipMalloc(&P->d_scal, ((size_t)N + 8) * 32));
   G16_HIP(hipMalloc(&P->d_tot, (n4 / kChunk + 8) * 32));
   G16_HIP(hipMalloc(&P->d_bad, 64));
   P->h_tot.resize(n4 / kChunk + 8);
   // w_4N^i and the 4N evaluations of L1 = NTT(iNTT(e_0))
-  k_powers<<<nblk(nblk(n4, kChunk)), 256, 0, st>>>(h_root((int)P->L + 2), (uint32_t)n4, P->d_om4);
+  k_powers<<<nblk(nblk(n4, kChunk)), 256, 0, st>>>(h_root((int)P->L + 2), (uint32_t)n4, P->d_T);
+  k_to_lazy<<<nblk(n4), 256, 0, st>>>(P->d_T, P->d_om4, n4);
   {
     G16_HIP(hipMemsetAsync(P->d_tmpN, 0, (size_t)N * 32, st));
     const FrM one_m = fp_one<FrParams>();
     G16_HIP(hipMemcpyAsync(P->d_tmpN, &one_m, 32, hipMemcpyHostToDevice, st));
     if ((rc = do_ifft(P->ntt_n, P->d_tmpN, P->d_tmpN2, P->d_lazy, st))) return rc;
     k_pad4<<<nblk(n4), 256, 0, st>>>(P->d_tmpN2, N, P->d_T);
-    if ((rc = do_fft(P->ntt_4n, P->d_T, P->d_l1, P->d_lazy, st))) return rc;
+    if ((rc = fft_to_lazy(P->ntt_4n, P->d_T, P->d_l1, st))) return rc;
   }
   G16_HIP(hipGetLastError());
   G16_HIP(hipStreamSynchronize(st));
@@ -769,13 +816,13 @@ int plonk_prove_impl(g16_plonk* P, const uint8_t* wtns, size_t wlen, const uint8
   for (int c = 0; c < 3; c++) k_gather<<<nblk(N), 256, 0, st>>>(P->d_w, P->d_map[c], ev[c], N);
   G16_HIP(hipGetLastError());
   // ---- round 1
-  auto to4t = [&](const FrM* evals, Pz pz, FrM* pol, FrM* ext) -> int {
+  auto to4t = [&](const FrM* evals, Pz pz, FrM* pol, F29* ext) -> int {
     int r = do_ifft(P->ntt_n, evals, P->d_tmpN, P->d_lazy, st);
     if (r) return r;
     k_blind<<<nblk(N + pz.n), 256, 0, st>>>(P->d_tmpN, N, pz, pol);
-    k_pad4<<<nblk(n4), 256, 0, st>>>(P->d_tmpN, N, ext);
+    k_pad4<<<nblk(n4), 256, 0, st>>>(P->d_tmpN, N, P->d_T);
     G16_HIP(hipGetLastError());
-    return do_fft(P->ntt_4n, ext, ext, P->d_lazy, st);
+    return fft_to_lazy(P->ntt_4n, P->d_T, ext, st);   // the 4N evaluations stay in the lazy format for round 3
   };
   Pz pza{{b[2], b[1], fp_zero<FrParams>()}, 2}, pzb{{b[4], b[3], fp_zero<FrParams>()}, 2}, pzc{{b[6], b[5], fp_zero<FrParams>()}, 2};
   if ((rc = to4t(P->d_A, pza, P->d_pa, P->d_A4))) return rc;
@@ -827,22 +874,25 @@ int plonk_prove_impl(g16_plonk* P, const uint8_t* wtns, size_t wlen, const uint8
     // the public-input polynomial on the 4N domain
     k_pi_evals<<<nblk(N), 256, 0, st>>>(P->d_A, P->nPublic, N, P->d_tmpN);
     if ((rc = do_ifft(P->ntt_n, P->d_tmpN, P->d_tmpN2, P->d_lazy, st))) return rc;
-    k_pad4<<<nblk(n4), 256, 0, st>>>(P->d_tmpN2, N, P->d_pi4);
-    if ((rc = do_fft(P->ntt_4n, P->d_pi4, P->d_pi4, P->d_lazy, st))) return rc;
+    k_pad4<<<nblk(n4), 256, 0, st>>>(P->d_tmpN2, N, P->d_T);
+    if ((rc = fft_to_lazy(P->ntt_4n, P->d_T, P->d_pi4, st))) return rc;
     R3Args a;
-    a.beta = beta; a.gamma = gamma; a.alpha = alpha; a.alpha2 = fp_sqr(alpha); a.k1 = P->k1; a.k2 = P->k2; a.w1 = P->w1;
-    for (int i = 0; i < 10; i++) a.b[i] = b[i];
+    auto lz = [](const FrM& x) { return fr29_from_fr(x); };
+    a.beta = lz(beta); a.gamma = lz(gamma); a.alpha = lz(alpha); a.alpha2 = lz(fp_sqr(alpha)); a.k1 = lz(P->k1); a.k2 = lz(P->k2);
+    a.w1 = lz(P->w1);
+    for (int i = 0; i < 10; i++) a.b[i] = lz(b[i]);
     const FrM i4 = h_root(2), one = fp_one<FrParams>(), two = fp_add(one, one), zero = fp_zero<FrParams>();
     const FrM m1 = fp_neg(one), m2 = fp_neg(two), four = fp_add(two, two), m8 = fp_neg(fp_add(four, four));
-    a.Z1[0] = zero; a.Z1[1] = fp_add(m1, i4); a.Z1[2] = m2; a.Z1[3] = fp_sub(m1, i4);
-    a.Z2[0] = zero; a.Z2[1] = fp_mul(m2, i4); a.Z2[2] = four; a.Z2[3] = fp_neg(fp_mul(m2, i4));
-    a.Z3[0] = zero; a.Z3[1] = fp_add(two, fp_mul(two, i4)); a.Z3[2] = m8; a.Z3[3] = fp_sub(two, fp_mul(two, i4));
-    R3Ptrs q{P->d_A4, P->d_B4, P->d_C4, P->d_Z4, P->d_ext[0], P->d_ext[1], P->d_ext[2], P->d_ext[3], P->d_ext[4],
-             P->d_ext[5], P->d_ext[6], P->d_ext[7], P->d_pi4, P->d_l1, P->d_om4};
-    k_round3<<<nblk(n4), 256, 0, st>>>(q, a, (uint32_t)n4, P->d_T, P->d_Tz);
+    a.one = lz(one);
+    a.Z1[0] = lz(zero); a.Z1[1] = lz(fp_add(m1, i4)); a.Z1[2] = lz(m2); a.Z1[3] = lz(fp_sub(m1, i4));
+    a.Z2[0] = lz(zero); a.Z2[1] = lz(fp_mul(m2, i4)); a.Z2[2] = lz(four); a.Z2[3] = lz(fp_neg(fp_mul(m2, i4)));
+    a.Z3[0] = lz(zero); a.Z3[1] = lz(fp_add(two, fp_mul(two, i4))); a.Z3[2] = lz(m8); a.Z3[3] = lz(fp_sub(two, fp_mul(two, i4)));
+    R3Ptrs q{P->d_A4, P->d_B4, P->d_C4, P->d_Z4, P->d_ext_l[0], P->d_ext_l[1], P->d_ext_l[2], P->d_ext_l[3], P->d_ext_l[4],
+             P->d_ext_l[5], P->d_ext_l[6], P->d_ext_l[7], P->d_pi4, P->d_l1, P->d_om4};
+    k_round3<<<nblk(n4), 256, 0, st>>>(q, a, (uint32_t)n4, P->d_lazy, P->d_lazy2);   // T and Tz, natural order, lazy
     G16_HIP(hipGetLastError());
-    if ((rc = do_ifft(P->ntt_4n, P->d_T, P->d_T, P->d_lazy, st))) return rc;
-    if ((rc = do_ifft(P->ntt_4n, P->d_Tz, P->d_Tz, P->d_lazy, st))) return rc;
+    if ((rc = ifft_from_lazy(P->ntt_4n, P->d_lazy, P->d_T, st))) return rc;
+    if ((rc = ifft_from_lazy(P->ntt_4n, P->d_lazy2, P->d_Tz, st))) return rc;
     G16_HIP(hipMemsetAsync(P->d_bad, 0, 8, st));
     k_div_zh<<<nblk(N), 256, 0, st>>>(P->d_T, P->d_Tz, N, P->d_bad);
     G16_HIP(hipGetLastError());
