@@ -101,6 +101,20 @@ def test_no_cpu_fallback(amd):
     with pytest.raises(amd.G16Error) as e:
         amd.multiexp(1, bytes(64), bytes(32))
     assert e.value.code == -4
+    # verifier, PLONK prover and PLONK setup: no CPU path either
+    zkey, _, vkey = amd.synth_setup(150, 6, 120, 2, 2)
+    with pytest.raises(amd.G16Error) as e:
+        amd.Verifier(vkey, 6)
+    assert e.value.code == -4
+    import plonk as pk
+    rows, _w = synth.make(24, 2, 12, 1)
+    pz = pk.write_zkey(pk.setup(24, 2, rows, tau=5))
+    with pytest.raises(amd.G16Error) as e:
+        amd.PlonkProver(pz)
+    assert e.value.code == -4
+    with pytest.raises(amd.G16Error) as e:
+        amd.plonk_setup(f.write_r1cs(24, 2, 0, synth.gen_circuit(24, 2, 12, 1)[1]), 1, device=0)
+    assert e.value.code == -4
     # the device path of the trapdoor setup, once selected, does not drop back to the host threads either
     amd.setup_device(0)
     try:
