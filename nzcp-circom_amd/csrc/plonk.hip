@@ -422,7 +422,8 @@ struct g16_plonk {
   int device = 0;
   uint32_t N = 0, L = 0, nVars = 0, nPublic = 0, nAdd = 0, nCons = 0, nBase = 0;
   FrM k1, k2, w1;
-  hipStream_t st = nullptr;
+  hipStream_t st = nullptr, st2 = nullptr;   // main chain (commitments); the 4N transforms of a round beside its commitments
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   NttTables ntt_n, ntt_4n;
   FrM* d_ext[8] = {};     // S1 S2 S3 (entries 5..7), 4N evaluations, canonical: round 2 reads them at the N-domain points
   F29* d_ext_l[8] = {};   // Qm Ql Qr Qo Qc S1 S2 S3, 4N evaluations in the lazy format: round 3
@@ -442,6 +443,8 @@ struct g16_plonk {
   F29 *d_A4 = nullptr, *d_B4 = nullptr, *d_C4 = nullptr, *d_Z4 = nullptr, *d_pi4 = nullptr;   // 4N evaluations, lazy format
   FrM *d_T = nullptr, *d_Tz = nullptr;  // 4N canonical words: padding scratch, then the quotient's coefficients
   FrM *d_tmpN = nullptr, *d_tmpN2 = nullptr, *d_tmpN3 = nullptr, *d_tmpN4 = nullptr;   // N-sized scratch
+  FrM *d_cA = nullptr, *d_cB = nullptr, *d_cC = nullptr, *d_cZ = nullptr;   // unblinded coefficients (the side stream pads them)
+  FrM *d_pi_ev = nullptr, *d_pi_co = nullptr;
   FrM *d_r = nullptr, *d_wxi = nullptr, *d_q = nullptr;
   FrM *d_tot = nullptr;                 // chunk totals / Horner partials
   F29 *d_lazy = nullptr, *d_lazy2 = nullptr;   // 4N lazy elements each: the transforms' working vectors (T and Tz in round 3)
@@ -457,13 +460,16 @@ struct g16_plonk {
     for (auto p : d_pol) if (p) (void)hipFree(p);
     for (auto p : d_map) if (p) (void)hipFree(p);
     void* v[] = {d_add_s1, d_add_s2, d_add_order, d_add_f1, d_add_f2, d_om4, d_l1, d_wraw, d_w, d_A, d_B, d_C, d_Z, d_pa, d_pb, d_pc,
-                 d_pz, d_A4, d_B4, d_C4, d_Z4, d_T, d_Tz, d_pi4, d_tmpN, d_tmpN2, d_tmpN3, d_tmpN4, d_r, d_wxi, d_q, d_tot, d_lazy, d_lazy2,
+                 d_pz, d_A4, d_B4, d_C4, d_Z4, d_T, d_Tz, d_pi4, d_tmpN, d_tmpN2, d_tmpN3, d_tmpN4, d_r, d_wxi, d_q, d_tot, d_lazy, d_lazy2, d_cA, d_cB, d_cC, d_cZ, d_pi_ev, d_pi_co,
                  d_scal, d_bad};
     for (void* p : v) if (p) (void)hipFree(p);
     if (ws) msm_workspace_destroy(ws);
     msm_group_destroy(srs);
     ntt_tables_destroy(ntt_n);
     ntt_tables_destroy(ntt_4n);
+    if (ev_fork) (void)hipEventDestroy(ev_fork);
+    if (ev_join) (void)hipEventDestroy(ev_join);
+    if (st2) (void)hipStreamDestroy(st2);
     if (st) (void)hipStreamDestroy(st);
   }
 };
@@ -573,6 +579,9 @@ int plonk_create_impl(const uint8_t* zkey, size_t len, int device, g16_plonk* P)
   P->device = device;
   G16_HIP(hipSetDevice(device));
   G16_HIP(hipStreamCreate(&P->st));
+  G16_HIP(hipStreamCreate(&P->st2));
+  G16_HIP(hipEventCreateWithFlags(&P->ev_fork, hipEventDisableTiming));
+  G16_HIP(hipEventCreateWithFlags(&P->ev_join, hipEventDisableTiming));
   hipStream_t st = P->st;
   if ((rc = ntt_tables_create(P->ntt_n, (int)P->L, st))) return rc;
   if ((rc = ntt_tables_create(P->ntt_4n, (int)P->L + 2, st))) return rc;
@@ -648,7 +657,8 @@ int plonk_create_impl(const uint8_t* zkey, size_t len, int device, g16_plonk* P)
   for (FrM** p : four) G16_HIP(hipMalloc(p, n4 * 32));
   F29** four_l[] = {&P->d_A4, &P->d_B4, &P->d_C4, &P->d_Z4, &P->d_pi4, &P->d_om4, &P->d_l1, &P->d_lazy, &P->d_lazy2};
   for (F29** p : four_l) G16_HIP(hipMalloc(p, n4 * sizeof(F29)));
-  FrM** one[] = {&P->d_A, &P->d_B, &P->d_C, &P->d_Z, &P->d_tmpN, &P->d_tmpN2, &P->d_tmpN3, &P->d_tmpN4};
+  FrM** one[] = {&P->d_A, &P->d_B, &P->d_C, &P->d_Z, &P->d_tmpN, &P->d_tmpN2, &P->d_tmpN3, &P->d_tmpN4,
+                 &P->d_cA, &P->d_cB, &P->d_cC, &P->d_cZ, &P->d_pi_ev, &P->d_pi_co};
   for (FrM** p : one) G16_HIP(hipMalloc(p, (size_t)N * 32));
   FrM** plus[] = {&P->d_pa, &P->d_pb, &P->d_pc, &P->d_pz, &P->d_r, &P->d_wxi, &P->d_q};
   for (FrM** p : plus) G16_HIP(hipMalloc(p, ((size_t)N + 8) * 32));
@@ -816,18 +826,35 @@ int plonk_prove_impl(g16_plonk* P, const uint8_t* wtns, size_t wlen, const uint8
   for (int c = 0; c < 3; c++) k_gather<<<nblk(N), 256, 0, st>>>(P->d_w, P->d_map[c], ev[c], N);
   G16_HIP(hipGetLastError());
   // ---- round 1
-  auto to4t = [&](const FrM* evals, Pz pz, FrM* pol, F29* ext) -> int {
-    int r = do_ifft(P->ntt_n, evals, P->d_tmpN, P->d_lazy, st);
+  // coefficients + blinded polynomial on the main stream; the 4N evaluations (needed in round 3 only) on the side
+  // stream, beside the round's commitments
+  hipStream_t st2 = P->st2;
+  auto to_pol = [&](const FrM* evals, Pz pz, FrM* pol, FrM* coefs) -> int {
+    int r = do_ifft(P->ntt_n, evals, coefs, P->d_lazy, st);
     if (r) return r;
-    k_blind<<<nblk(N + pz.n), 256, 0, st>>>(P->d_tmpN, N, pz, pol);
-    k_pad4<<<nblk(n4), 256, 0, st>>>(P->d_tmpN, N, P->d_T);
+    k_blind<<<nblk(N + pz.n), 256, 0, st>>>(coefs, N, pz, pol);
     G16_HIP(hipGetLastError());
-    return fft_to_lazy(P->ntt_4n, P->d_T, ext, st);   // the 4N evaluations stay in the lazy format for round 3
+    return G16_OK;
+  };
+  auto ext_of = [&](const FrM* coefs, F29* ext) -> int {
+    k_pad4<<<nblk(n4), 256, 0, st2>>>(coefs, N, P->d_T);
+    G16_HIP(hipGetLastError());
+    return fft_to_lazy(P->ntt_4n, P->d_T, ext, st2);   // the evaluations stay in the lazy format for round 3
   };
   Pz pza{{b[2], b[1], fp_zero<FrParams>()}, 2}, pzb{{b[4], b[3], fp_zero<FrParams>()}, 2}, pzc{{b[6], b[5], fp_zero<FrParams>()}, 2};
-  if ((rc = to4t(P->d_A, pza, P->d_pa, P->d_A4))) return rc;
-  if ((rc = to4t(P->d_B, pzb, P->d_pb, P->d_B4))) return rc;
-  if ((rc = to4t(P->d_C, pzc, P->d_pc, P->d_C4))) return rc;
+  if ((rc = to_pol(P->d_A, pza, P->d_pa, P->d_cA))) return rc;
+  if ((rc = to_pol(P->d_B, pzb, P->d_pb, P->d_cB))) return rc;
+  if ((rc = to_pol(P->d_C, pzc, P->d_pc, P->d_cC))) return rc;
+  G16_HIP(hipEventRecord(P->ev_fork, st));
+  G16_HIP(hipStreamWaitEvent(st2, P->ev_fork, 0));
+  if ((rc = ext_of(P->d_cA, P->d_A4))) return rc;
+  if ((rc = ext_of(P->d_cB, P->d_B4))) return rc;
+  if ((rc = ext_of(P->d_cC, P->d_C4))) return rc;
+  {   // the public-input polynomial on the 4N domain
+    k_pi_evals<<<nblk(N), 256, 0, st2>>>(P->d_A, P->nPublic, N, P->d_pi_ev);
+    if ((rc = do_ifft(P->ntt_n, P->d_pi_ev, P->d_pi_co, P->d_lazy2, st2))) return rc;
+    if ((rc = ext_of(P->d_pi_co, P->d_pi4))) return rc;
+  }
   if ((rc = commit(P, P->d_pa, N + 2, &pr->A))) return rc;
   if ((rc = commit(P, P->d_pb, N + 2, &pr->B))) return rc;
   if ((rc = commit(P, P->d_pc, N + 2, &pr->C))) return rc;
@@ -863,7 +890,11 @@ int plonk_prove_impl(g16_plonk* P, const uint8_t* wtns, size_t wlen, const uint8
     G16_HIP(hipStreamSynchronize(st));
   }
   Pz pzz{{b[9], b[8], b[7]}, 3};
-  if ((rc = to4t(P->d_Z, pzz, P->d_pz, P->d_Z4))) return rc;
+  if ((rc = to_pol(P->d_Z, pzz, P->d_pz, P->d_cZ))) return rc;
+  G16_HIP(hipEventRecord(P->ev_fork, st));
+  G16_HIP(hipStreamWaitEvent(st2, P->ev_fork, 0));
+  if ((rc = ext_of(P->d_cZ, P->d_Z4))) return rc;
+  G16_HIP(hipEventRecord(P->ev_join, st2));
   if ((rc = commit(P, P->d_pz, N + 3, &pr->Z))) return rc;
   lap(1);
   // ---- round 3
@@ -871,11 +902,7 @@ int plonk_prove_impl(g16_plonk* P, const uint8_t* wtns, size_t wlen, const uint8
   put_g1_be(tr, pr->Z);
   const FrM alpha = hash_to_fr(tr);
   {
-    // the public-input polynomial on the 4N domain
-    k_pi_evals<<<nblk(N), 256, 0, st>>>(P->d_A, P->nPublic, N, P->d_tmpN);
-    if ((rc = do_ifft(P->ntt_n, P->d_tmpN, P->d_tmpN2, P->d_lazy, st))) return rc;
-    k_pad4<<<nblk(n4), 256, 0, st>>>(P->d_tmpN2, N, P->d_T);
-    if ((rc = fft_to_lazy(P->ntt_4n, P->d_T, P->d_pi4, st))) return rc;
+    G16_HIP(hipStreamWaitEvent(st, P->ev_join, 0));   // A4, B4, C4, the public-input polynomial and Z4 are in place
     R3Args a;
     auto lz = [](const FrM& x) { return fr29_from_fr(x); };
     a.beta = lz(beta); a.gamma = lz(gamma); a.alpha = lz(alpha); a.alpha2 = lz(fp_sqr(alpha)); a.k1 = lz(P->k1); a.k2 = lz(P->k2);

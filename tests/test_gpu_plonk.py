@@ -94,3 +94,40 @@ def test_full_size_nzcp_example_as_plonk(amd):
     bad = list(pub)
     bad[100] = str(1 - int(bad[100]))
     assert not pk.verify(vk, [int(x) for x in bad], pk.proof_from_obj(proof))
+
+
+def test_setup_edge_shapes_of_r1cs_rows(amd):
+    """The branches of the R1CS -> PLONK conversion the random generator never takes: a constant times a linear
+    combination (A or B has only the constant wire), an empty A (the row is C = 0), repeated wires inside one linear
+    combination, long linear combinations (chains of addition gates), a row with constants on both sides of a product."""
+    R = b.R
+    n, p = 12, 2
+    # wires: 0 = 1, 1..2 public, 3..11 private
+    w = [1, 6, 35, 2, 3, 5, 7, 11, 13, 0, 0, 0]
+    w[9] = (w[3] + 2 * w[4] + 3 * w[5] + 4 * w[6] + 5 * w[7] + 6 * w[8]) % R           # long sum
+    w[10] = (w[9] + 7) * (w[3] + 1) % R                                                # constants on both factors
+    w[11] = 4 * (w[4] + w[5]) % R
+    rows = [
+        ([(3, 1)], [(4, 1)], [(1, 1)]),                                                 # 2 * 3 = 6 (public)
+        ([(5, 1)], [(6, 1)], [(2, 1)]),                                                 # 5 * 7 = 35 (public)
+        ([(0, 1)], [(3, 1), (4, 2), (5, 3), (6, 4), (7, 5), (8, 6)], [(9, 1)]),          # A = constant 1
+        ([(9, 1), (0, 7)], [(3, 1), (0, 1)], [(10, 1)]),                                # (w9 + 7)(w3 + 1) = w10
+        ([(4, 1), (5, 1)], [(0, 4)], [(11, 1)]),                                        # B = constant 4
+        ([], [(3, 1)], [(11, 1), (4, R - 4), (5, R - 4)]),                              # A empty: C = 0
+        ([(3, 1), (3, 2), (4, 1)], [(5, 1), (5, 1)], [(3, 30), (4, 10)]),               # repeated wires: (3 w3 + w4)(2 w5) = 30 w3 + 10 w4
+    ]
+    assert synth.check_r1cs(rows, w) if hasattr(synth, "check_r1cs") else True
+    gates, adds, pnv = pk.r1cs_to_plonk(n, p, rows)
+    assert pk.check_gates(gates, p, pk.extend_witness(w, adds)) and len(adds) >= 5
+    import groth16 as g
+    seed = 21
+    zk = pk.setup(n, p, rows, g.trapdoor(seed + 1)["tau"])
+    zkey = amd.plonk_setup(f.write_r1cs(n, p, 0, rows), seed, device=0)
+    assert zkey == pk.write_zkey(zk)
+    prover = amd.PlonkProver(zkey)
+    rng = synth.Xoshiro(5)
+    bl = {i: rng.rand_fr() for i in range(1, 10)}
+    proof, pub = prover.prove(f.write_wtns(w), [bl[i] for i in range(1, 10)])
+    prover.close()
+    assert proof == pk.proof_obj(pk.prove(zk, w, bl)[0]) and pub == ["6", "35"]
+    assert pk.verify(pk.vkey(zk), [6, 35], pk.proof_from_obj(proof))
