@@ -434,7 +434,11 @@ struct g16_plonk {
   std::vector<uint32_t> level_start;
   F29 *d_om4 = nullptr, *d_l1 = nullptr;   // w_4N^i and L1 on the 4N domain, lazy format
   MsmGroup srs;
-  MsmWorkspace* ws = nullptr;
+  MsmWorkspace* ws = nullptr;             // slot 0 of the commitment lanes (on the main stream)
+  MsmWorkspace* wsx[2] = {nullptr, nullptr};   // slots 1, 2: independent commitments of a round run side by side
+  hipStream_t mst[2] = {nullptr, nullptr};
+  Fr* d_scalx[2] = {nullptr, nullptr};
+  hipEvent_t ev_pol = nullptr;
   // per-proof scratch
   Fr* d_wraw = nullptr;                 // witness as uploaded (standard form)
   FrM* d_w = nullptr;                   // extended witness, Montgomery
@@ -464,6 +468,10 @@ struct g16_plonk {
                  d_scal, d_bad};
     for (void* p : v) if (p) (void)hipFree(p);
     if (ws) msm_workspace_destroy(ws);
+    for (auto w : wsx) if (w) msm_workspace_destroy(w);
+    for (auto p : d_scalx) if (p) (void)hipFree(p);
+    for (auto x : mst) if (x) (void)hipStreamDestroy(x);
+    if (ev_pol) (void)hipEventDestroy(ev_pol);
     msm_group_destroy(srs);
     ntt_tables_destroy(ntt_n);
     ntt_tables_destroy(ntt_4n);
@@ -690,6 +698,12 @@ int plonk_create_impl(const uint8_t* zkey, size_t len, int device, g16_plonk* P)
   if ((rc = msm_group_create(P->srs, &sec, 1, cfg))) return rc;
   if (P->srs.n != N + 6) { set_error("zkey: a power of tau is the point at infinity"); return G16_E_FORMAT; }
   if ((rc = msm_workspace_create(&P->ws, P->srs))) return rc;
+  for (int k = 0; k < 2; k++) {
+    if ((rc = msm_workspace_create(&P->wsx[k], P->srs))) return rc;
+    G16_HIP(hipStreamCreate(&P->mst[k]));
+    G16_HIP(hipMalloc(&P->d_scalx[k], ((size_t)N + 8) * 32));
+  }
+  G16_HIP(hipEventCreateWithFlags(&P->ev_pol, hipEventDisableTiming));
   return G16_OK;
 }
 
@@ -699,16 +713,41 @@ struct PlonkProofM {   // points affine Montgomery, evaluations Montgomery
 };
 
 // commitment of `len` Montgomery coefficients starting at d_coefs: sum coef_i [tau^i]
-int commit(g16_plonk* P, const FrM* d_coefs, uint32_t len, G1Affine* out) {
+// Commitments: slot 0 runs on the main stream, slots 1 and 2 on their own streams behind an event of the main stream
+// (the coefficients are written there), so that the independent commitments of a round overlap their latency-bound
+// front ends and reduce tails with each other's bucket accumulation.
+int commit_launch(g16_plonk* P, int slot, const FrM* d_coefs, uint32_t len) {
   const uint32_t np = P->N + 6;
-  k_from_mont_pad<<<nblk(np), 256, 0, P->st>>>(d_coefs, len, P->d_scal, np);
+  hipStream_t s = slot ? P->mst[slot - 1] : P->st;
+  Fr* scal = slot ? P->d_scalx[slot - 1] : P->d_scal;
+  if (slot) {
+    G16_HIP(hipEventRecord(P->ev_pol, P->st));
+    G16_HIP(hipStreamWaitEvent(s, P->ev_pol, 0));
+  }
+  k_from_mont_pad<<<nblk(np), 256, 0, s>>>(d_coefs, len, scal, np);
   G16_HIP(hipGetLastError());
-  int rc = msm_launch(P->srs, P->ws, P->d_scal, P->st, P->st);
-  if (rc) return rc;
+  return msm_launch(P->srs, slot ? P->wsx[slot - 1] : P->ws, scal, s, s);
+}
+int commit_collect(g16_plonk* P, int slot, G1Affine* out) {
   MsmResult res;
-  if ((rc = msm_collect(P->srs, P->ws, &res))) return rc;
+  int rc = msm_collect(P->srs, slot ? P->wsx[slot - 1] : P->ws, &res);
+  if (rc) return rc;
   xyzz_to_affine(*out, res.g1[0]);
   return G16_OK;
+}
+int commit(g16_plonk* P, const FrM* d_coefs, uint32_t len, G1Affine* out) {
+  int rc = commit_launch(P, 0, d_coefs, len);
+  return rc ? rc : commit_collect(P, 0, out);
+}
+// three (or two) independent commitments at once
+int commit3(g16_plonk* P, const FrM* const coefs[3], const uint32_t lens[3], G1Affine* const outs[3], int count) {
+  int rc = G16_OK;
+  for (int k = count - 1; k >= 0 && !rc; k--) rc = commit_launch(P, k, coefs[k], lens[k]);   // side slots first: their event precedes slot 0's kernels
+  for (int k = 0; k < count; k++) {
+    const int r = commit_collect(P, k, outs[k]);
+    if (r && !rc) rc = r;
+  }
+  return rc;
 }
 
 // sum_i P[i] x^i over n device coefficients: chunked Horner on the device, the chunk values combined on the host
@@ -855,9 +894,12 @@ int plonk_prove_impl(g16_plonk* P, const uint8_t* wtns, size_t wlen, const uint8
     if ((rc = do_ifft(P->ntt_n, P->d_pi_ev, P->d_pi_co, P->d_lazy2, st2))) return rc;
     if ((rc = ext_of(P->d_pi_co, P->d_pi4))) return rc;
   }
-  if ((rc = commit(P, P->d_pa, N + 2, &pr->A))) return rc;
-  if ((rc = commit(P, P->d_pb, N + 2, &pr->B))) return rc;
-  if ((rc = commit(P, P->d_pc, N + 2, &pr->C))) return rc;
+  {
+    const FrM* cf[3] = {P->d_pa, P->d_pb, P->d_pc};
+    const uint32_t ln[3] = {N + 2, N + 2, N + 2};
+    G1Affine* o[3] = {&pr->A, &pr->B, &pr->C};
+    if ((rc = commit3(P, cf, ln, o, 3))) return rc;
+  }
   lap(0);
   // ---- round 2
   std::vector<uint8_t> tr;
@@ -929,9 +971,12 @@ int plonk_prove_impl(g16_plonk* P, const uint8_t* wtns, size_t wlen, const uint8
     if (bad[0]) { set_error("T Polynomial is not divisible"); return G16_E_STATE; }
     if (bad[1]) { set_error("Tz Polynomial is not well calculated"); return G16_E_STATE; }
   }
-  if ((rc = commit(P, P->d_T, N, &pr->T1))) return rc;
-  if ((rc = commit(P, P->d_T + N, N, &pr->T2))) return rc;
-  if ((rc = commit(P, P->d_T + 2 * (size_t)N, N + 6, &pr->T3))) return rc;
+  {
+    const FrM* cf[3] = {P->d_T, P->d_T + N, P->d_T + 2 * (size_t)N};
+    const uint32_t ln[3] = {N, N, N + 6};
+    G1Affine* o[3] = {&pr->T1, &pr->T2, &pr->T3};
+    if ((rc = commit3(P, cf, ln, o, 3))) return rc;
+  }
   lap(2);
   // ---- round 4
   tr.clear();
@@ -983,11 +1028,15 @@ int plonk_prove_impl(g16_plonk* P, const uint8_t* wtns, size_t wlen, const uint8
   k_pol_wxi<<<nblk(N + 6), 256, 0, st>>>(P->d_T, P->d_r, P->d_pa, P->d_pb, P->d_pc, P->d_pol[5], P->d_pol[6], a5, N, P->d_wxi);
   G16_HIP(hipGetLastError());
   if ((rc = div_pol1(P, P->d_wxi, N + 6, xi, P->d_q))) return rc;
-  if ((rc = commit(P, P->d_q, N + 6, &pr->Wxi))) return rc;
-  G16_HIP(hipMemcpyAsync(P->d_wxi, P->d_pz, ((size_t)N + 3) * 32, hipMemcpyDeviceToDevice, st));
-  k_sub0<<<1, 1, 0, st>>>(P->d_wxi, pr->ezw);
-  if ((rc = div_pol1(P, P->d_wxi, N + 3, xiw, P->d_q))) return rc;
-  if ((rc = commit(P, P->d_q, N + 3, &pr->Wxiw))) return rc;
+  G16_HIP(hipMemcpyAsync(P->d_r, P->d_pz, ((size_t)N + 3) * 32, hipMemcpyDeviceToDevice, st));   // (r is spent)
+  k_sub0<<<1, 1, 0, st>>>(P->d_r, pr->ezw);
+  if ((rc = div_pol1(P, P->d_r, N + 3, xiw, P->d_wxi))) return rc;
+  {
+    const FrM* cf[3] = {P->d_q, P->d_wxi, nullptr};
+    const uint32_t ln[3] = {N + 6, N + 3, 0};
+    G1Affine* o[3] = {&pr->Wxi, &pr->Wxiw, nullptr};
+    if ((rc = commit3(P, cf, ln, o, 2))) return rc;
+  }
   lap(4);
   P->last_ms[5] = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - tstart).count();
   return G16_OK;
