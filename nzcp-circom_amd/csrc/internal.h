@@ -57,6 +57,9 @@ int ntt_coset_scale(const NttTables& t, F29* const* vecs, int nvec, hipStream_t 
 // through the bit-reversal permutation; export can fold in the 1/N of the inverse transform)
 int ntt_import(const NttTables& t, const Fr* in, F29* out, bool bitrev, hipStream_t st);
 int ntt_export(const NttTables& t, const F29* in, Fr* out, bool bitrev, bool scale_ninv, hipStream_t st);
+// inverse transform + coset table + forward transform of `nvec` vectors in place, the two middle passes fused in LDS;
+// join_p != nullptr (nvec == 3: a, b, c): the last forward pass also joins, join_p[i] = plain(a'b' - c') (vectors consumed)
+int ntt_coset_roundtrip(const NttTables& t, F29* const* vecs, int nvec, Fr* join_p, hipStream_t st);
 // ntt_dit_forward of a, b, c with the join fused into the last pass (the vectors are consumed)
 int ntt_dit_forward_join(const NttTables& t, F29* a, F29* b, F29* c, Fr* p_std, hipStream_t st);
 // P[i] = plain(a[i]*b[i] - c[i])   (qap_joinABC + batchFromMontgomery)

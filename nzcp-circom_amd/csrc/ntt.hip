@@ -121,6 +121,29 @@ __global__ __launch_bounds__(kThreads) void ntt_pass_kernel(VecPtrs vecs, const 
   }
 }
 
+// The LAST inverse (DIF) pass and the FIRST forward (DIT) pass act on the same tiles -- the contiguous 2^tile_log
+// elements, index bits [0, tile_log) -- with the coset table between them: one kernel runs the inverse stages, the
+// table product and the forward stages on the tile in LDS, so the half-way vectors (coefficients x coset factors, in
+// bit-reversed order) never go to HBM: one read + one write of every vector less per odd-coset evaluation.
+__global__ __launch_bounds__(kThreads) void ntt_mid_pass_kernel(VecPtrs vecs, const F29* __restrict__ tw_inv,
+                                                                const F29* __restrict__ tw_fwd, int L, int tile_log,
+                                                                const F29* __restrict__ post) {
+  extern __shared__ __align__(16) unsigned char ntt_lds[];
+  F29* tile = reinterpret_cast<F29*>(ntt_lds);
+  F29* __restrict__ x = vecs.p[blockIdx.y];
+  const uint32_t tile_n = 1u << tile_log;
+  const size_t base = (size_t)blockIdx.x << tile_log;
+  auto gidx = [&](uint32_t e) -> size_t { return base + e; };
+  for (uint32_t e = threadIdx.x; e < tile_n; e += kThreads) tile[e] = fr29_weak_reduce(x[base + e]);
+  __syncthreads();
+  ntt_tile_stages(tile, tw_inv, gidx, tile_n, L, 0, tile_log, 0, 1);
+  // (< 16 r after the inverse stages; the product with the table entry is < 1.1 r: what the forward stages expect)
+  for (uint32_t e = threadIdx.x; e < tile_n; e += kThreads) tile[e] = fr29_mul(tile[e], post[base + e]);
+  __syncthreads();
+  ntt_tile_stages(tile, tw_fwd, gidx, tile_n, L, 0, tile_log, 0, 0);
+  for (uint32_t e = threadIdx.x; e < tile_n; e += kThreads) x[base + e] = tile[e];
+}
+
 // The LAST forward (DIT) pass of the three vectors A, B, C fused with qap_joinABC + batchFromMontgomery: a
 // workgroup runs the pass on the same tile of A, then B, then C (one 20 KiB LDS tile, reused), keeps its own
 // elements in registers and writes only P[g] = plain(A'[g] B'[g] - C'[g]): the three transformed vectors never
@@ -237,6 +260,8 @@ int ntt_tables_create(NttTables& t, int L, hipStream_t st) {
   }
   G16_HIP(hipFuncSetAttribute((const void*)ntt_pass_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                               (int)(sizeof(F29) << kTileLogCap)));
+  G16_HIP(hipFuncSetAttribute((const void*)ntt_mid_pass_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)(sizeof(F29) << kTileLogCap)));
   G16_HIP(hipFuncSetAttribute((const void*)ntt_last_pass_join_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize,
                               (int)(sizeof(F29) << kTileLogCap)));
   G16_HIP(hipFuncSetAttribute((const void*)ntt_last_pass_join_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -317,6 +342,46 @@ int ntt_dit_forward_join(const NttTables& t, F29* a, F29* b, F29* c, Fr* p_std, 
   else if (t.tile_log == 10) G16_JOIN_LAUNCH(4);
   else G16_JOIN_LAUNCH(8);
 #undef G16_JOIN_LAUNCH
+  G16_HIP(hipGetLastError());
+  return G16_OK;
+}
+
+// Odd-coset evaluation of `nvec` vectors in place: inverse transform, coset table, forward transform, with the
+// middle two passes fused (ntt_mid_pass_kernel).  join_p != nullptr (three vectors a, b, c): the last forward pass
+// joins as well and writes join_p[i] = plain(a'[i] b'[i] - c'[i]) (the vectors are then left half-transformed).
+int ntt_coset_roundtrip(const NttTables& t, F29* const* vecs, int nvec, Fr* join_p, hipStream_t st) {
+  if (nvec < 1 || nvec > 4 || (join_p && nvec != 3)) { set_error("ntt: bad vector count"); return G16_E_ARG; }
+  const int np = (int)t.passes.size();
+  if (t.L == 0 || np < 2 || t.passes[0].lo_bits != 0 || t.passes[0].S != t.tile_log) {   // tiny domains: unfused
+    int rc = ntt_dif_inverse_coset(t, vecs, nvec, st);
+    if (rc) return rc;
+    return join_p ? ntt_dit_forward_join(t, vecs[0], vecs[1], vecs[2], join_p, st) : ntt_dit_forward(t, vecs, nvec, st);
+  }
+  if (join_p && t.tile_log > 11) { set_error("ntt: tile too large for the fused join"); return G16_E_ARG; }
+  VecPtrs vp{};
+  for (int i = 0; i < nvec; i++) vp.p[i] = vecs[i];
+  const unsigned ntiles = 1u << (t.L - t.tile_log);
+  const size_t lds = sizeof(F29) << t.tile_log;
+  for (int k = np - 1; k >= 1; k--) {   // inverse passes on the high bits
+    const NttPass& p = t.passes[k];
+    ntt_pass_kernel<<<dim3(ntiles, nvec), kThreads, lds, st>>>(vp, t.tw_inv, t.L, t.tile_log, p.lo_bits, p.S, p.tb, 1, nullptr);
+  }
+  ntt_mid_pass_kernel<<<dim3(ntiles, nvec), kThreads, lds, st>>>(vp, t.tw_inv, t.tw_fwd, t.L, t.tile_log, t.coset);
+  const int last_plain = join_p ? np - 2 : np - 1;
+  for (int k = 1; k <= last_plain; k++) {   // forward passes on the high bits
+    const NttPass& p = t.passes[k];
+    ntt_pass_kernel<<<dim3(ntiles, nvec), kThreads, lds, st>>>(vp, t.tw_fwd, t.L, t.tile_log, p.lo_bits, p.S, p.tb, 0, nullptr);
+  }
+  if (join_p) {
+    const NttPass& p = t.passes[np - 1];
+#define G16_JOIN_LAUNCH(EPT) \
+  ntt_last_pass_join_kernel<EPT><<<ntiles, kThreads, lds, st>>>(vp, t.tw_fwd, t.L, t.tile_log, p.lo_bits, p.S, p.tb, join_p)
+    if (t.tile_log <= 8) G16_JOIN_LAUNCH(1);
+    else if (t.tile_log == 9) G16_JOIN_LAUNCH(2);
+    else if (t.tile_log == 10) G16_JOIN_LAUNCH(4);
+    else G16_JOIN_LAUNCH(8);
+#undef G16_JOIN_LAUNCH
+  }
   G16_HIP(hipGetLastError());
   return G16_OK;
 }

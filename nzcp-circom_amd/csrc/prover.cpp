@@ -620,8 +620,10 @@ static int launch_qap_ntt(g16_prover* P, ProofCtx& c, const Fr* d_w, uint32_t ma
   int rc;
   if ((rc = qap_eval(P->csr, d_w, c.d_a, c.d_b, c.d_c, c.st))) return rc;
   G16_HIP(hipEventRecord(c.ev[3], c.st));
+  static const bool mid = !(getenv("G16_NO_FUSED_MID") && atoi(getenv("G16_NO_FUSED_MID")));
   if (fuse_join) {   // all three vectors here: the last forward pass writes P directly
     F29* v3[3] = {c.d_a, c.d_b, c.d_c};
+    if (mid) return ntt_coset_roundtrip(P->ntt, v3, 3, c.d_p, c.st);
     if ((rc = ntt_dif_inverse_coset(P->ntt, v3, 3, c.st))) return rc;
     return ntt_dit_forward_join(P->ntt, c.d_a, c.d_b, c.d_c, c.d_p, c.st);
   }
@@ -631,6 +633,7 @@ static int launch_qap_ntt(g16_prover* P, ProofCtx& c, const Fr* d_w, uint32_t ma
   for (int v = 0; v < 3; v++)
     if (mask & (1u << v)) vecs[nv++] = all[v];
   if (nv) {
+    if (mid) return ntt_coset_roundtrip(P->ntt, vecs, nv, nullptr, c.st);
     if ((rc = ntt_dif_inverse_coset(P->ntt, vecs, nv, c.st))) return rc;   // iNTT + (1/N, w_2N^i) table
     if ((rc = ntt_dit_forward(P->ntt, vecs, nv, c.st))) return rc;
   }
