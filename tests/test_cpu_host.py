@@ -175,3 +175,39 @@ def test_nzcp_fixed_circuit_tool(tmp_path):
     vk = json.load(open(out / "verification_key.json"))
     assert vk["nPublic"] == 513 and len(vk["IC"]) == 514 and vk["protocol"] == "groth16"
     assert (out / "circuit.r1cs").read_bytes()[:4] == b"r1cs" and (out / "circuit.zkey").read_bytes()[:4] == b"zkey"
+
+
+def test_parsers_survive_mutated_keys(amd):
+    """The C ABI takes untrusted buffers: thousands of mutated Groth16 and PLONK keys (flipped header bytes, truncations,
+    overwritten 32-bit fields, absurd section sizes) must come back as G16_E_FORMAT -- or pass the parser and stop at
+    the device check on this GPU-less box -- never crash."""
+    import random
+    import struct
+    import torch
+    import plonk as pk
+    if torch.cuda.is_available():
+        pytest.skip("GPU present: a mutated key that parses would go on to the device")
+    z = open(golden_path("tiny.zkey"), "rb").read()
+    rows, _w = synth.make(24, 2, 12, 1)
+    pz = pk.write_zkey(pk.setup(24, 2, rows, tau=5))
+    rng = random.Random(1)
+    for buf, ctor in ((z, amd.Prover), (pz, amd.PlonkProver)):
+        codes = set()
+        for _ in range(1500):
+            b = bytearray(buf)
+            k = rng.randrange(4)
+            if k == 0:
+                for _j in range(rng.randrange(1, 4)):
+                    b[rng.randrange(min(len(b), 600))] = rng.randrange(256)
+            elif k == 1:
+                b = b[:rng.randrange(len(b))]
+            elif k == 2:
+                i = rng.randrange(len(b) - 4)
+                b[i:i + 4] = struct.pack("<I", rng.choice([0, 1, 0xffffffff, 0x7fffffff, rng.randrange(1 << 32)]))
+            else:
+                i = 12 + rng.randrange(200)
+                b[i:i + 8] = struct.pack("<Q", rng.choice([0, 1, len(b), 1 << 40, (1 << 64) - 1]))
+            with pytest.raises(amd.G16Error) as e:
+                ctor(bytes(b))
+            codes.add(e.value.code)
+        assert codes <= {-2, -4, -1} and -2 in codes
