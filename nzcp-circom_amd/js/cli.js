@@ -10,6 +10,12 @@ const { groth16 } = require("./index.js");
 
 async function main(argv) {
   let a = argv.slice(2);
+  if (a[0] === "zkey" && a[1] === "export" && a[2] === "verificationkey") {   // snarkjs zkey export verificationkey <zkey> [vk.json]
+    const { exportVerificationKey } = require("./index.js");
+    const [zk, out = "verification_key.json"] = a.slice(3);
+    fs.writeFileSync(out, JSON.stringify(exportVerificationKey(zk), null, 1), "utf-8");
+    return;
+  }
   if (a[0] === "plonk" && a[1] === "prove") {   // snarkjs plonk prove <circuit.zkey> <witness.wtns> [proof.json] [public.json]
     const [zk, wt, proofFile = "proof.json", publicFile = "public.json"] = a.slice(2).filter((x) => !x.startsWith("--"));
     const { plonk } = require("./index.js");

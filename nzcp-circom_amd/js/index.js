@@ -223,6 +223,63 @@ const plonk = {
   },
 };
 
+// ------------------------------------------------------------------ zkey export verificationkey (host-only: header reads)
+// snarkjs `zKey.exportVerificationKey(zkey)` / CLI `zkey export verificationkey <zkey> <vk.json>` -- the second line of
+// the reference's PLONK flow (/root/reference/Makefile:32).  Groth16 and PLONK keys; points leave Montgomery form here
+// (BigInt arithmetic, a few hundred values).  Groth16: `vk_alphabeta_12` -- redundant, snarkjs's verifier does not
+// read it -- is not written.
+const FQ = 21888242871839275222246405745257275088696311157297823662689037894645226208583n;
+const FR = 21888242871839275222246405745257275088548364400416034343698204186575808495617n;
+function modpow(b, e, m) { let r = 1n; b %= m; while (e > 0n) { if (e & 1n) r = (r * b) % m; b = (b * b) % m; e >>= 1n; } return r; }
+const RQ_INV = modpow((1n << 256n) % FQ, FQ - 2n, FQ), RR_INV = modpow((1n << 256n) % FR, FR - 2n, FR);
+function leBig(buf, off) { let n = 0n; for (let i = 31; i >= 0; i--) n = (n << 8n) | BigInt(buf[off + i]); return n; }
+function sections(buf, what) {
+  if (buf.length < 12 || buf.toString("latin1", 0, 4) !== what) throw new Error(`${what}: Invalid File format`);
+  const n = buf.readUInt32LE(8), out = {};
+  let pos = 12;
+  for (let i = 0; i < n; i++) {
+    if (pos + 12 > buf.length) throw new Error(`${what}: Invalid File format`);
+    const id = buf.readUInt32LE(pos), size = Number(buf.readBigUInt64LE(pos + 4));
+    pos += 12;
+    if (size > buf.length - pos) throw new Error(`${what}: Invalid File format`);
+    if (!(id in out)) out[id] = { pos, size };
+    pos += size;
+  }
+  return out;
+}
+function exportVerificationKey(zkey) {
+  const b = toBuffer(zkey, "zkey"), s = sections(b, "zkey");
+  if (!s[1] || !s[2]) throw new Error("zkey: Invalid File format");
+  const proto = b.readUInt32LE(s[1].pos);
+  const fq = (o) => ((leBig(b, o) * RQ_INV) % FQ).toString();
+  const g1 = (o) => (isZero(b, o, 64) ? ["0", "1", "0"] : [fq(o), fq(o + 32), "1"]);
+  const g2 = (o) => (isZero(b, o, 128) ? [["0", "0"], ["1", "0"], ["0", "0"]]
+    : [[fq(o), fq(o + 32)], [fq(o + 64), fq(o + 96)], ["1", "0"]]);
+  let h = s[2].pos + 72;   // past n8q, q, n8r, r
+  if (proto === 1) {
+    const nPublic = b.readUInt32LE(h + 4);
+    h += 12;
+    const vk = { protocol: "groth16", curve: "bn128", nPublic, vk_alpha_1: g1(h), vk_beta_2: g2(h + 128), vk_gamma_2: g2(h + 256),
+      vk_delta_2: g2(h + 448), IC: [] };
+    if (!s[3] || s[3].size !== (nPublic + 1) * 64) throw new Error("zkey: Invalid File format");
+    for (let i = 0; i <= nPublic; i++) vk.IC.push(g1(s[3].pos + 64 * i));
+    return vk;
+  }
+  if (proto === 2) {
+    const nPublic = b.readUInt32LE(h + 4), domainSize = b.readUInt32LE(h + 8);
+    const power = 31 - Math.clz32(domainSize);
+    h += 20;
+    const fr = (o) => ((leBig(b, o) * RR_INV) % FR).toString();
+    const vk = { protocol: "plonk", curve: "bn128", nPublic, power, k1: fr(h), k2: fr(h + 32) };
+    h += 64;
+    for (const k of ["Qm", "Ql", "Qr", "Qo", "Qc", "S1", "S2", "S3"]) { vk[k] = g1(h); h += 64; }
+    vk.X_2 = g2(h);
+    vk.w = modpow(5n, (FR - 1n) >> BigInt(power), FR).toString();   // Fr.w[power]: 5^((r-1)/2^power)
+    return vk;
+  }
+  throw new Error("zkey: unknown protocol");
+}
+
 const groth16 = {
   // snarkjs: groth16.verify(vk_verifier, publicSignals, proof[, logger]) -> boolean
   async verify(vk, publicSignals, proof, opts = {}) {
@@ -247,4 +304,4 @@ const groth16 = {
   createProver,
 };
 
-module.exports = { groth16, plonk, PlonkProver, plonkProofObject, createProver, Prover, createVerifier, Verifier, proofObject, publicSignals, proofBytes, vkeyBytes };
+module.exports = { groth16, plonk, zKey: { exportVerificationKey }, exportVerificationKey, PlonkProver, plonkProofObject, createProver, Prover, createVerifier, Verifier, proofObject, publicSignals, proofBytes, vkeyBytes };

@@ -118,6 +118,42 @@ def test_node_verify_and_cli(addon, tmp_path):
 
 
 @needs_node
+def test_zkey_export_verificationkey(tmp_path):
+    """`snarkjs zkey export verificationkey` (the second line of the reference's PLONK flow, Makefile:32) from the Node
+    host: host-only header reads.  Groth16: the golden key's verification key as the oracle wrote it; PLONK: the
+    commitments, k1, k2, X_2 and w of an oracle-written key."""
+    import bn254 as b
+    import plonk as pk
+    import synth
+    meta = json.load(open(golden_path("small.json")))
+    rows, _w = synth.make(24, 2, 12, 1)
+    zk = pk.setup(24, 2, rows, tau=4242)
+    zf = tmp_path / "p.zkey"
+    zf.write_bytes(pk.write_zkey(zk))
+    out = tmp_path / "vk.json"
+    r = subprocess.run(["node", os.path.join(JS, "cli.js"), "zkey", "export", "verificationkey", golden_path("small.zkey"), str(out)],
+                       capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    got = json.loads(out.read_text())
+    want = {k: meta["vkey"][k] for k in meta["vkey"] if k != "vk_alphabeta_12"}
+    assert got == want and list(got.keys())[:3] == ["protocol", "curve", "nPublic"]
+    r = subprocess.run(["node", os.path.join(JS, "cli.js"), "zkey", "export", "verificationkey", str(zf), str(out)],
+                       capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    got = json.loads(out.read_text())
+
+    def g1(P):
+        return [str(P[0]), str(P[1]), "1"]
+    assert got["protocol"] == "plonk" and got["nPublic"] == 2 and got["power"] == zk["power"]
+    assert (got["k1"], got["k2"]) == (str(zk["k1"]), str(zk["k2"]))
+    for k in ("Qm", "Ql", "Qr", "Qo", "Qc", "S1", "S2", "S3"):
+        assert got[k] == (g1(zk[k]) if zk[k] is not None else ["0", "1", "0"])
+    X2 = zk["X_2"]
+    assert got["X_2"] == [[str(X2[0][0]), str(X2[0][1])], [str(X2[1][0]), str(X2[1][1])], ["1", "0"]]
+    assert got["w"] == str(b.fr_root(zk["power"]))
+
+
+@needs_node
 @pytest.mark.gpu
 def test_node_plonk_prove(addon, tmp_path):
     """snarkjs `plonk.prove(zkey, wtns)` through the Node host: with the oracle's blinding the proof object is the
