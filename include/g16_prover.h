@@ -316,6 +316,15 @@ void g16_plonk_destroy(g16_plonk* p);
  * not read it; snarkjs does). */
 int g16_plonk_setup(const uint8_t* r1cs, size_t r1cs_len, uint64_t seed, int device, int with_lagrange, uint8_t** zkey,
                     size_t* zkey_len);
+/* `snarkjs plonk setup c.r1cs pot.ptau c.zkey` itself (/root/reference/Makefile:31: powersOfTau28_hez_final_22.ptau):
+ * the powers come from a .ptau v1 image ([EXT] snarkjs powersoftau_utils.js; sections 1-3 are read), the eight
+ * selector / sigma commitments are MSMs over them on the device.  "circuit too big for this power of tau ceremony.
+ * G > 2**P" when the gates do not fit. */
+int g16_plonk_setup_ptau(const uint8_t* r1cs, size_t r1cs_len, const uint8_t* ptau, size_t ptau_len, int device,
+                         int with_lagrange, uint8_t** zkey, size_t* zkey_len);
+/* the same from / to files (inputs mapped read-only): for hosts whose buffers end at 2 GB (Node.js) -- a 2^22 ceremony
+ * file is 4.6 GB, the key it yields 5.8 GB without the Lagrange section */
+int g16_plonk_setup_files(const char* r1cs_path, const char* ptau_path, const char* zkey_path, int device, int with_lagrange);
 
 #ifdef __cplusplus
 }

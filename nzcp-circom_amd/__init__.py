@@ -66,7 +66,7 @@ EXPORTS = ["g16_create", "g16_prove", "g16_prove_batch", "g16_stage_witness", "g
            "g16_multi_create", "g16_multi_prove", "g16_multi_get_info", "g16_multi_destroy",
            "g16_nzcp_gadget", "g16_nzcp_circuit_setup", "g16_setup_device",
            "g16_verifier_create", "g16_verify_batch", "g16_verifier_timings", "g16_verifier_destroy", "g16_pairing_op",
-           "g16_plonk_create", "g16_plonk_prove", "g16_plonk_get_info", "g16_plonk_destroy", "g16_plonk_setup", "g16_plonk_timings"]
+           "g16_plonk_create", "g16_plonk_prove", "g16_plonk_get_info", "g16_plonk_destroy", "g16_plonk_setup", "g16_plonk_timings", "g16_plonk_setup_ptau", "g16_plonk_setup_files"]
 
 
 def load():
@@ -132,6 +132,8 @@ def load():
     lib.g16_plonk_destroy.restype = None
     lib.g16_plonk_timings.argtypes = [vp, C.POINTER(C.c_float)]
     lib.g16_plonk_setup.argtypes = [C.c_char_p, sz, C.c_uint64, C.c_int, C.c_int, C.POINTER(vp), C.POINTER(sz)]
+    lib.g16_plonk_setup_files.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.c_int, C.c_int]
+    lib.g16_plonk_setup_ptau.argtypes = [C.c_char_p, sz, C.c_char_p, sz, C.c_int, C.c_int, C.POINTER(vp), C.POINTER(sz)]
     lib.g16_r1cs_setup.argtypes = [C.c_char_p, sz, C.c_uint64, C.c_int, C.POINTER(vp), C.POINTER(sz), C.POINTER(vp), C.POINTER(sz)]
     lib.g16_sha256_chain_setup.argtypes = [C.c_uint32, C.c_char_p, C.c_uint64, C.c_int] + [C.c_void_p] * 8
     lib.g16_sha256_message_setup.argtypes = [C.c_char_p, C.c_uint32, C.c_uint64, C.c_int] + [C.c_void_p] * 8
@@ -643,6 +645,13 @@ def plonk_setup(r1cs, seed, device=0, with_lagrange=True):
     """Test-only PLONK setup with a known tau: .r1cs bytes -> snarkjs-layout PLONK .zkey bytes."""
     z, zl = C.c_void_p(), C.c_size_t()
     _check(load().g16_plonk_setup(r1cs, len(r1cs), seed, device, 1 if with_lagrange else 0, C.byref(z), C.byref(zl)))
+    return _take(z, zl)
+
+
+def plonk_setup_ptau(r1cs, ptau, device=0, with_lagrange=True):
+    """`snarkjs plonk setup c.r1cs pot.ptau c.zkey`: .r1cs and .ptau bytes -> PLONK .zkey bytes."""
+    z, zl = C.c_void_p(), C.c_size_t()
+    _check(load().g16_plonk_setup_ptau(r1cs, len(r1cs), ptau, len(ptau), device, 1 if with_lagrange else 0, C.byref(z), C.byref(zl)))
     return _take(z, zl)
 
 

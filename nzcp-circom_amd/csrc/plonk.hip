@@ -1091,6 +1091,51 @@ int plonk_setup_polys(int device, int L, const Fr* const evals[8], uint8_t* cons
 }
 }  // namespace g16
 
+// setup with a real .ptau (synth.cpp::g16_plonk_setup_ptau): the eight commitments sum coef_i [tau^i]G1 by MSM over the
+// first N powers; coefs[k] = N Montgomery words on the host, out = 8 affine Montgomery points
+namespace g16 {
+int plonk_setup_commit(int device, const uint8_t* tau_g1, uint32_t N, const uint8_t* const coefs[8], uint8_t* out) {
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { set_error("plonk setup: no HIP device"); return G16_E_NOGPU; }
+  if (device < 0 || device >= ndev) { set_error("plonk setup: bad device ordinal"); return G16_E_ARG; }
+  G16_HIP(hipSetDevice(device));
+  MsmGroup grp;
+  MsmWorkspace* ws = nullptr;
+  MsmSectionIn sec;
+  sec.bases_host = tau_g1;
+  sec.n_total = N;
+  MsmConfig cfg;
+  cfg.dense = true;
+  int rc = msm_group_create(grp, &sec, 1, cfg);
+  if (!rc && grp.n != N) { set_error("ptau: a power of tau is the point at infinity"); rc = G16_E_FORMAT; }
+  if (!rc) rc = msm_workspace_create(&ws, grp);
+  hipStream_t st = nullptr;
+  FrM* d_co = nullptr;
+  Fr* d_sc = nullptr;
+  if (!rc && (hipStreamCreate(&st) != hipSuccess || hipMalloc(&d_co, (size_t)N * 32) != hipSuccess ||
+              hipMalloc(&d_sc, (size_t)N * 32) != hipSuccess)) { set_error("plonk setup: HIP allocation failed"); rc = G16_E_HIP; }
+  for (int k = 0; k < 8 && !rc; k++) {
+    if (hipMemcpyAsync(d_co, coefs[k], (size_t)N * 32, hipMemcpyHostToDevice, st) != hipSuccess) { set_error("plonk setup: upload failed"); rc = G16_E_HIP; break; }
+    k_from_mont_pad<<<nblk(N), 256, 0, st>>>(d_co, N, d_sc, N);
+    rc = msm_launch(grp, ws, d_sc, st, st);
+    MsmResult res;
+    if (!rc) rc = msm_collect(grp, ws, &res);
+    if (!rc) {
+      G1Affine a;
+      xyzz_to_affine(a, res.g1[0]);
+      memcpy(out + (size_t)k * 64, &a, 64);
+    }
+  }
+  if (st) (void)hipStreamSynchronize(st);
+  if (d_co) (void)hipFree(d_co);
+  if (d_sc) (void)hipFree(d_sc);
+  if (ws) msm_workspace_destroy(ws);
+  msm_group_destroy(grp);
+  if (st) (void)hipStreamDestroy(st);
+  return rc;
+}
+}  // namespace g16
+
 namespace {
 
 void g1_std(uint8_t out[64], const G1Affine& p) {

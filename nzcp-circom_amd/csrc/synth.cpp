@@ -1218,9 +1218,21 @@ struct PlonkBuilder {
 int plonk_setup_polys(int device, int L, const Fr* const evals[8], uint8_t* const out[8]);
 }  // namespace g16
 
-extern "C" int g16_plonk_setup(const uint8_t* r1cs, size_t r1cs_len, uint64_t seed, int device, int with_lagrange,
-                               uint8_t** zkey, size_t* zkey_len) {
-  if (!r1cs || !zkey || !zkey_len) { set_error("NULL argument"); return G16_E_ARG; }
+namespace g16 {
+int plonk_setup_commit(int device, const uint8_t* tau_g1, uint32_t N, const uint8_t* const coefs[8], uint8_t* out);   // plonk.hip
+}
+// where the powers of tau come from: a known tau (test-only), or the points of a .ptau file
+struct PlonkTauSrc {
+  bool known = true;
+  uint64_t seed = 0;
+  const uint8_t* tau_g1 = nullptr;   // .ptau section 2: [tau^i]G1, affine Montgomery LE
+  uint64_t n_g1 = 0;
+  const uint8_t* tau_g2_1 = nullptr; // .ptau section 3, point 1: [tau]G2
+  uint32_t power = 0;
+};
+static int plonk_setup_core(const uint8_t* r1cs, size_t r1cs_len, const PlonkTauSrc& src, int device, int with_lagrange,
+                            uint8_t** zkey, size_t* zkey_len) {
+  const uint64_t seed = src.seed;
   Circuit c;
   int rc = read_r1cs(r1cs, r1cs_len, c);
   if (rc) return rc;
@@ -1255,6 +1267,10 @@ extern "C" int g16_plonk_setup(const uint8_t* r1cs, size_t r1cs_len, uint64_t se
   while (((size_t)1 << L) < ng) L++;
   if (L > 24) { set_error("plonk setup: circuit too large (more than 2^24 gates)"); return G16_E_ARG; }
   const size_t N = (size_t)1 << L;
+  if (!src.known && ((uint32_t)L > src.power || N + 6 > src.n_g1)) {
+    set_error("circuit too big for this power of tau ceremony. " + std::to_string(ng) + " > 2**" + std::to_string(src.power));
+    return G16_E_ARG;
+  }
   Xo trng(seed + 1);
   FrM tau;
   do { tau = trng.rand_fr(); } while (fp_is_zero(tau));
@@ -1338,6 +1354,30 @@ extern "C" int g16_plonk_setup(const uint8_t* r1cs, size_t r1cs_len, uint64_t se
       }
     }
   }
+  auto write_header = [&](const uint8_t* commitments /* 8 x 64 */, const uint8_t* x2 /* 128 */) {
+    uint8_t* q = sp[2];
+    static const uint32_t Qp[8] = G16_FQ_P, Rp[8] = G16_FR_P;
+    uint32_t v32 = 32;
+    memcpy(q, &v32, 4); memcpy(q + 4, Qp, 32); memcpy(q + 36, &v32, 4); memcpy(q + 40, Rp, 32);
+    q += 72;
+    const uint32_t hv[5] = {pb.nv, c.p, (uint32_t)N, (uint32_t)pb.adds.size(), (uint32_t)ng};
+    memcpy(q, hv, 20); q += 20;
+    memcpy(q, k1.v, 32); memcpy(q + 32, k2.v, 32); q += 64;
+    memcpy(q, commitments, 8 * 64);
+    memcpy(q + 8 * 64, x2, 128);
+  };
+  if (!src.known) {
+    // a real ceremony's points: the first N + 6 powers are copied, the commitments are MSMs over them on the device
+    memcpy(sp[14], src.tau_g1, (N + 6) * 64);
+    const uint8_t* cf[8];
+    for (int k = 0; k < 8; k++) cf[k] = k < 5 ? sp[7 + k] : sp[12] + (size_t)(k - 5) * polb;
+    uint8_t cm[8 * 64];
+    if ((rc = plonk_setup_commit(device, src.tau_g1, (uint32_t)N, cf, cm))) { free(z.p); return rc; }
+    write_header(cm, src.tau_g2_1);
+    *zkey = z.p;
+    *zkey_len = z.len;
+    return G16_OK;
+  }
   // powers of tau and the commitments [P(tau)]G (tau is known: one fixed-base multiplication each)
   const int threads = (int)std::thread::hardware_concurrency() > 0 ? (int)std::thread::hardware_concurrency() : 1;
   FixedBase<FqOps> fb1;
@@ -1360,14 +1400,6 @@ extern "C" int g16_plonk_setup(const uint8_t* r1cs, size_t r1cs_len, uint64_t se
     }
   }
   {
-    uint8_t* q = sp[2];
-    static const uint32_t Qp[8] = G16_FQ_P, Rp[8] = G16_FR_P;
-    uint32_t v32 = 32;
-    memcpy(q, &v32, 4); memcpy(q + 4, Qp, 32); memcpy(q + 36, &v32, 4); memcpy(q + 40, Rp, 32);
-    q += 72;
-    const uint32_t hv[5] = {pb.nv, c.p, (uint32_t)N, (uint32_t)pb.adds.size(), (uint32_t)ng};
-    memcpy(q, hv, 20); q += 20;
-    memcpy(q, k1.v, 32); memcpy(q + 32, k2.v, 32); q += 64;
     FrM cm[8];
     for (int k = 0; k < 8; k++) {   // P(tau) by Horner over the coefficients just written
       const uint8_t* co = k < 5 ? sp[7 + k] : sp[12] + (size_t)(k - 5) * polb;
@@ -1379,12 +1411,113 @@ extern "C" int g16_plonk_setup(const uint8_t* r1cs, size_t r1cs_len, uint64_t se
       }
       cm[k] = acc;
     }
-    fixed_mul_many(fb1, cm, 8, q, 1);
-    q += 8 * 64;
-    fixed_mul_many(fb2, &tau, 1, q, 1);
+    uint8_t cmb[8 * 64], x2[128];
+    fixed_mul_many(fb1, cm, 8, cmb, 1);
+    fixed_mul_many(fb2, &tau, 1, x2, 1);
+    write_header(cmb, x2);
   }
   *zkey = z.p;
   *zkey_len = z.len;
+  return G16_OK;
+}
+
+extern "C" int g16_plonk_setup(const uint8_t* r1cs, size_t r1cs_len, uint64_t seed, int device, int with_lagrange,
+                               uint8_t** zkey, size_t* zkey_len) {
+  if (!r1cs || !zkey || !zkey_len) { set_error("NULL argument"); return G16_E_ARG; }
+  PlonkTauSrc src;
+  src.known = true;
+  src.seed = seed;
+  return plonk_setup_core(r1cs, r1cs_len, src, device, with_lagrange, zkey, zkey_len);
+}
+
+// `snarkjs plonk setup c.r1cs pot.ptau c.zkey` (/root/reference/Makefile:31) with a REAL powers-of-tau file: .ptau v1
+// ([EXT] snarkjs powersoftau_utils.js: section 1 = n8, q, power, ceremonyPower; section 2 = 2^(power+1) - 1 points
+// [tau^i]G1; section 3 = 2^power points [tau^i]G2; affine Montgomery LE).  The N + 6 powers are copied into the key and
+// the eight selector / sigma commitments are MSMs over them on the device.
+extern "C" int g16_plonk_setup_ptau(const uint8_t* r1cs, size_t r1cs_len, const uint8_t* ptau, size_t ptau_len, int device,
+                                    int with_lagrange, uint8_t** zkey, size_t* zkey_len) {
+  if (!r1cs || !ptau || !zkey || !zkey_len) { set_error("NULL argument"); return G16_E_ARG; }
+  if (ptau_len < 12 || memcmp(ptau, "ptau", 4) != 0) { set_error("ptau: Invalid File format"); return G16_E_FORMAT; }
+  uint32_t version, nsec;
+  memcpy(&version, ptau + 4, 4);
+  memcpy(&nsec, ptau + 8, 4);
+  if (version > 1) { set_error("Version not supported"); return G16_E_FORMAT; }
+  const uint8_t* sp[4] = {nullptr, nullptr, nullptr, nullptr};
+  uint64_t sl[4] = {0, 0, 0, 0};
+  size_t pos = 12;
+  for (uint32_t i = 0; i < nsec; i++) {
+    if (pos + 12 > ptau_len) { set_error("ptau: Invalid File format"); return G16_E_FORMAT; }
+    uint32_t id;
+    uint64_t sz;
+    memcpy(&id, ptau + pos, 4);
+    memcpy(&sz, ptau + pos + 4, 8);
+    pos += 12;
+    if (sz > ptau_len - pos) { set_error("ptau: Invalid File format"); return G16_E_FORMAT; }
+    if (id >= 1 && id <= 3 && !sp[id]) { sp[id] = ptau + pos; sl[id] = sz; }
+    pos += sz;
+  }
+  static const uint32_t Qp[8] = G16_FQ_P;
+  uint32_t n8 = 0;
+  if (sp[1] && sl[1] >= 4) memcpy(&n8, sp[1], 4);
+  if (!sp[1] || !sp[2] || !sp[3] || sl[1] < 4 + 32 + 8 || n8 != 32 || memcmp(sp[1] + 4, Qp, 32) != 0) {
+    set_error("ptau: Invalid File format (bn128 powers of tau expected)");
+    return G16_E_FORMAT;
+  }
+  PlonkTauSrc src;
+  src.known = false;
+  memcpy(&src.power, sp[1] + 36, 4);
+  if (src.power > 28 || sl[2] < (((uint64_t)2 << src.power) - 1) * 64 || sl[3] < 2 * 128) {
+    set_error("ptau: Invalid File format");
+    return G16_E_FORMAT;
+  }
+  src.tau_g1 = sp[2];
+  src.n_g1 = sl[2] / 64;
+  src.tau_g2_1 = sp[3] + 128;
+  return plonk_setup_core(r1cs, r1cs_len, src, device, with_lagrange, zkey, zkey_len);
+}
+
+// File-path form of g16_plonk_setup_ptau for hosts that cannot hold a ceremony file in one buffer (a Node.js Buffer
+// ends at 2 GB; powersOfTau28_hez_final_22.ptau is 4.6 GB): the inputs are mapped read-only, the key is written out.
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+extern "C" int g16_plonk_setup_files(const char* r1cs_path, const char* ptau_path, const char* zkey_path, int device,
+                                     int with_lagrange) {
+  if (!r1cs_path || !ptau_path || !zkey_path) { set_error("NULL argument"); return G16_E_ARG; }
+  struct Map {
+    void* p = MAP_FAILED;
+    size_t len = 0;
+    int open_ro(const char* path) {
+      const int fd = open(path, O_RDONLY);
+      if (fd < 0) { set_error(std::string(path) + ": cannot open"); return G16_E_ARG; }
+      struct stat sb;
+      if (fstat(fd, &sb) != 0 || sb.st_size <= 0) { close(fd); set_error(std::string(path) + ": Invalid File format"); return G16_E_FORMAT; }
+      len = (size_t)sb.st_size;
+      p = mmap(nullptr, len, PROT_READ, MAP_PRIVATE, fd, 0);
+      close(fd);
+      if (p == MAP_FAILED) { set_error(std::string(path) + ": cannot map"); return G16_E_STATE; }
+      return G16_OK;
+    }
+    ~Map() { if (p != MAP_FAILED) munmap(p, len); }
+  } r1cs, ptau;
+  int rc = r1cs.open_ro(r1cs_path);
+  if (!rc) rc = ptau.open_ro(ptau_path);
+  if (rc) return rc;
+  uint8_t* z = nullptr;
+  size_t zl = 0;
+  rc = g16_plonk_setup_ptau((const uint8_t*)r1cs.p, r1cs.len, (const uint8_t*)ptau.p, ptau.len, device, with_lagrange, &z, &zl);
+  if (rc) return rc;
+  FILE* f = fopen(zkey_path, "wb");
+  if (!f) { free(z); set_error(std::string(zkey_path) + ": cannot create"); return G16_E_ARG; }
+  size_t off = 0;
+  while (off < zl) {
+    const size_t chunk = zl - off < ((size_t)1 << 28) ? zl - off : ((size_t)1 << 28);
+    if (fwrite(z + off, 1, chunk, f) != chunk) { fclose(f); free(z); set_error(std::string(zkey_path) + ": write failed"); return G16_E_STATE; }
+    off += chunk;
+  }
+  free(z);
+  if (fclose(f) != 0) { set_error(std::string(zkey_path) + ": write failed"); return G16_E_STATE; }
   return G16_OK;
 }
 

@@ -19,6 +19,7 @@
  *           plonkCreate(zkey: Buffer, device) -> Promise<phandle>                                  (g16_plonk_create)
  *           plonkProve(phandle, wtns: Buffer, blinding: Buffer(288)|null) -> Promise<{proof: Buffer(832), pub: Buffer}>
  *           plonkDestroy(phandle)
+ *           plonkSetupFiles(r1csPath, ptauPath, zkeyPath, device, withLagrange) -> Promise<undefined>   (g16_plonk_setup_files)
  */
 #include <node_api.h>
 #include <stdlib.h>
@@ -647,6 +648,59 @@ static napi_value js_plonk_destroy(napi_env env, napi_callback_info info) {
   return NULL;
 }
 
+/* plonk setup from / to files (the inputs may exceed a Buffer) */
+typedef struct {
+  napi_async_work work;
+  napi_deferred deferred;
+  char r1cs[1024], ptau[1024], zkey[1024];
+  int device, lagrange, rc;
+  char err[512];
+} sjob_t;
+static void sjob_execute(napi_env env, void* data) {
+  sjob_t* j = (sjob_t*)data;
+  j->rc = g16_plonk_setup_files(j->r1cs, j->ptau, j->zkey, j->device, j->lagrange);
+  if (j->rc) { strncpy(j->err, g16_last_error(), sizeof(j->err) - 1); j->err[sizeof(j->err) - 1] = 0; }
+}
+static void sjob_complete(napi_env env, napi_status status, void* data) {
+  sjob_t* j = (sjob_t*)data;
+  if (status != napi_ok || j->rc) {
+    napi_value msg, err;
+    napi_create_string_utf8(env, j->rc ? j->err : "g16 addon: async work cancelled", NAPI_AUTO_LENGTH, &msg);
+    napi_create_error(env, NULL, msg, &err);
+    napi_reject_deferred(env, j->deferred, err);
+  } else {
+    napi_value undef;
+    napi_get_undefined(env, &undef);
+    napi_resolve_deferred(env, j->deferred, undef);
+  }
+  napi_delete_async_work(env, j->work);
+  free(j);
+}
+static napi_value js_plonk_setup_files(napi_env env, napi_callback_info info) {
+  size_t argc = 5;
+  napi_value argv[5], promise, resname;
+  NAPI_OK(napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
+  if (argc < 3) { napi_throw_type_error(env, NULL, "plonkSetupFiles(r1csPath, ptauPath, zkeyPath, device, withLagrange)"); return NULL; }
+  sjob_t* j = (sjob_t*)calloc(1, sizeof(sjob_t));
+  size_t n = 0;
+  if (napi_get_value_string_utf8(env, argv[0], j->r1cs, sizeof(j->r1cs), &n) != napi_ok ||
+      napi_get_value_string_utf8(env, argv[1], j->ptau, sizeof(j->ptau), &n) != napi_ok ||
+      napi_get_value_string_utf8(env, argv[2], j->zkey, sizeof(j->zkey), &n) != napi_ok) {
+    free(j);
+    napi_throw_type_error(env, NULL, "plonkSetupFiles: three path strings expected");
+    return NULL;
+  }
+  int32_t v = 0;
+  if (argc > 3 && napi_get_value_int32(env, argv[3], &v) == napi_ok) j->device = v;
+  v = 0;
+  if (argc > 4 && napi_get_value_int32(env, argv[4], &v) == napi_ok) j->lagrange = v;
+  NAPI_OK(napi_create_promise(env, &j->deferred, &promise));
+  NAPI_OK(napi_create_string_utf8(env, "g16_plonk_setup_files", NAPI_AUTO_LENGTH, &resname));
+  NAPI_OK(napi_create_async_work(env, NULL, resname, sjob_execute, sjob_complete, j, &j->work));
+  NAPI_OK(napi_queue_async_work(env, j->work));
+  return promise;
+}
+
 static napi_value init(napi_env env, napi_value exports) {
   napi_property_descriptor props[] = {
       {"create", NULL, js_create, NULL, NULL, NULL, napi_default, NULL},
@@ -661,6 +715,7 @@ static napi_value init(napi_env env, napi_value exports) {
       {"plonkCreate", NULL, js_plonk_create, NULL, NULL, NULL, napi_default, NULL},
       {"plonkProve", NULL, js_plonk_prove, NULL, NULL, NULL, napi_default, NULL},
       {"plonkDestroy", NULL, js_plonk_destroy, NULL, NULL, NULL, napi_default, NULL},
+      {"plonkSetupFiles", NULL, js_plonk_setup_files, NULL, NULL, NULL, napi_default, NULL},
   };
   NAPI_OK(napi_define_properties(env, exports, sizeof(props) / sizeof(props[0]), props));
   return exports;

@@ -16,6 +16,13 @@ async function main(argv) {
     fs.writeFileSync(out, JSON.stringify(exportVerificationKey(zk), null, 1), "utf-8");
     return;
   }
+  if (a[0] === "plonk" && a[1] === "setup") {   // snarkjs plonk setup <circuit.r1cs> <powersoftau.ptau> <circuit.zkey>
+    const pos = a.slice(2).filter((x) => !x.startsWith("--"));
+    if (pos.length < 3) { console.error("usage: cli.js plonk setup <circuit.r1cs> <pot.ptau> <circuit.zkey> [--lagrange]"); process.exit(2); }
+    const { plonk } = require("./index.js");
+    await plonk.setup(pos[0], pos[1], pos[2], { lagrange: a.includes("--lagrange") });
+    return;
+  }
   if (a[0] === "plonk" && a[1] === "prove") {   // snarkjs plonk prove <circuit.zkey> <witness.wtns> [proof.json] [public.json]
     const [zk, wt, proofFile = "proof.json", publicFile = "public.json"] = a.slice(2).filter((x) => !x.startsWith("--"));
     const { plonk } = require("./index.js");

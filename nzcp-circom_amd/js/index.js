@@ -221,6 +221,13 @@ const plonk = {
   async createProver(zkey, opts = {}) {
     return new PlonkProver(await native().plonkCreate(toBuffer(zkey, "zkey"), opts.device | 0));
   },
+  // snarkjs: plonk.setup(r1csName, ptauName, zkeyName[, logger]) -- file names (a ceremony file exceeds a Buffer).
+  // opts.lagrange: also write the Lagrange section 13 (snarkjs's own prover reads it; this one does not -- it is
+  // nPublic x 5N field elements, 344 GB for 513 public signals at N = 2^22).
+  async setup(r1csName, ptauName, zkeyName, opts = {}) {
+    if (opts && typeof opts.debug === "function") opts = {};
+    await native().plonkSetupFiles(String(r1csName), String(ptauName), String(zkeyName), opts.device | 0, opts.lagrange ? 1 : 0);
+  },
 };
 
 // ------------------------------------------------------------------ zkey export verificationkey (host-only: header reads)

@@ -531,3 +531,21 @@ def vkey_from_zkey(buf):
         pos += 64
     vk["X_2"] = g2_from_lem(h[pos:pos + 128])
     return vk
+
+
+def write_ptau(power, tau):
+    """A powers-of-tau file as snarkjs's powersoftau_utils.js lays it out (.ptau v1): section 1 = n8, q, power,
+    ceremonyPower; 2 = [tau^i]G1, i < 2^(power+1) - 1; 3 = [tau^i]G2, i < 2^power; 4-6 the alpha/beta points (dummies
+    here: the PLONK setup does not read them); 7 = contributions (none).  Test fixture generator: tau is known."""
+    import struct
+    from bn254 import Q
+    from formats import le, g1_to_lem, g2_to_lem, write_binfile, N8
+    n = 1 << power
+    s1 = struct.pack("<I", N8) + le(Q) + struct.pack("<II", power, power)
+    pw = [pow(tau, i, R) for i in range(2 * n - 1)]
+    s2 = b"".join(g1_to_lem(P) for P in G1.gen_mul_many(pw))
+    s3 = b"".join(g2_to_lem(P) for P in G2.gen_mul_many(pw[:n]))
+    s4 = b"".join(g1_to_lem(G1_GEN) for _ in range(n))
+    s5 = s4
+    s6 = g2_to_lem(G2_GEN)
+    return write_binfile("ptau", 1, [(1, s1), (2, s2), (3, s3), (4, s4), (5, s5), (6, s6), (7, struct.pack("<I", 0))])

@@ -131,3 +131,29 @@ def test_setup_edge_shapes_of_r1cs_rows(amd):
     prover.close()
     assert proof == pk.proof_obj(pk.prove(zk, w, bl)[0]) and pub == ["6", "35"]
     assert pk.verify(pk.vkey(zk), [6, 35], pk.proof_from_obj(proof))
+
+
+def test_setup_from_a_ptau_file_equals_oracle(amd):
+    """`snarkjs plonk setup c.r1cs pot.ptau c.zkey` (/root/reference/Makefile:31) with the powers taken from a .ptau
+    image (written by the oracle for a known tau): the zkey -- commitments by MSM over the file's points this time --
+    equals the oracle's for that tau byte for byte; a circuit that does not fit the ceremony is refused with snarkjs's text."""
+    n, p, m, seed = 300, 20, 260, 9
+    _, rows, _ = synth.gen_circuit(n, p, m, seed)
+    r1cs = f.write_r1cs(n, p, 0, rows)
+    rows_w, w = synth.make(n, p, m, seed)
+    tau = 0x5eed1234abcdef
+    zk = pk.setup(n, p, rows_w, tau)
+    ptau = pk.write_ptau(zk["power"] + 1, tau)          # a bigger ceremony than needed, as in practice
+    zkey = amd.plonk_setup_ptau(r1cs, ptau, device=0)
+    assert zkey == pk.write_zkey(zk)
+    prover = amd.PlonkProver(zkey)
+    proof, pub = prover.prove(f.write_wtns(w))
+    prover.close()
+    assert pk.verify(pk.vkey_from_zkey(zkey), [int(x) for x in pub], pk.proof_from_obj(proof))
+    small = pk.write_ptau(zk["power"] - 1, tau)
+    with pytest.raises(amd.G16Error) as e:
+        amd.plonk_setup_ptau(r1cs, small, device=0)
+    assert "circuit too big for this power of tau ceremony" in str(e.value) and "2**%d" % (zk["power"] - 1) in str(e.value)
+    with pytest.raises(amd.G16Error) as e:
+        amd.plonk_setup_ptau(r1cs, ptau[:500], device=0)
+    assert "Invalid File format" in str(e.value)

@@ -155,6 +155,39 @@ def test_zkey_export_verificationkey(tmp_path):
 
 @needs_node
 @pytest.mark.gpu
+def test_node_plonk_setup_from_ptau_files(addon, tmp_path):
+    """The reference's own scripted flow (/root/reference/Makefile:31-32) through the Node CLI, on the GPU:
+    `plonk setup c.r1cs pot.ptau c.zkey` (file names; powers from a .ptau the oracle wrote for a known tau), then
+    `zkey export verificationkey` and `plonk prove` on the result -- the key equals the oracle's byte for byte and the
+    proof passes the oracle's verifier with the exported verification key's commitments."""
+    import plonk as pk
+    import synth
+    n, p, m, seed = 60, 5, 40, 3
+    _, rows, _ = synth.gen_circuit(n, p, m, seed)
+    rows_w, w = synth.make(n, p, m, seed)
+    tau = 271828182845
+    zk = pk.setup(n, p, rows_w, tau)
+    rf, pf, zf, wf = tmp_path / "c.r1cs", tmp_path / "pot.ptau", tmp_path / "c.zkey", tmp_path / "w.wtns"
+    rf.write_bytes(f.write_r1cs(n, p, 0, rows))
+    pf.write_bytes(pk.write_ptau(zk["power"], tau))
+    wf.write_bytes(f.write_wtns(w))
+    cli = os.path.join(JS, "cli.js")
+    r = subprocess.run(["node", cli, "plonk", "setup", str(rf), str(pf), str(zf), "--lagrange"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    assert zf.read_bytes() == pk.write_zkey(zk)
+    vkf, prf, puf = tmp_path / "vk.json", tmp_path / "proof.json", tmp_path / "public.json"
+    assert subprocess.run(["node", cli, "zkey", "export", "verificationkey", str(zf), str(vkf)], capture_output=True, timeout=120).returncode == 0
+    assert subprocess.run(["node", cli, "plonk", "prove", str(zf), str(wf), str(prf), str(puf)], capture_output=True, timeout=300).returncode == 0
+    vkj = json.loads(vkf.read_text())
+    vk = pk.vkey(zk)
+    assert vkj["Qm"] == ([str(vk["Qm"][0]), str(vk["Qm"][1]), "1"] if vk["Qm"] else ["0", "1", "0"])
+    assert pk.verify(vk, [int(x) for x in json.loads(puf.read_text())], pk.proof_from_obj(json.loads(prf.read_text())))
+    r = subprocess.run(["node", cli, "plonk", "setup", str(rf), str(tmp_path / "missing.ptau"), str(zf)], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 1 and "cannot open" in r.stderr
+
+
+@needs_node
+@pytest.mark.gpu
 def test_node_plonk_prove(addon, tmp_path):
     """snarkjs `plonk.prove(zkey, wtns)` through the Node host: with the oracle's blinding the proof object is the
     oracle's (oracle/plonk.py), with fresh randomness it still passes the oracle's KZG verifier; the CLI twin writes
