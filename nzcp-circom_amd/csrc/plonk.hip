@@ -594,8 +594,10 @@ int plonk_create_impl(const uint8_t* zkey, size_t len, int device, g16_plonk* P)
   if ((rc = ntt_tables_create(P->ntt_n, (int)P->L, st))) return rc;
   if ((rc = ntt_tables_create(P->ntt_4n, (int)P->L + 2, st))) return rc;
   // polynomials: coefficients (N) then evaluations (4N)
-  FrM* d_stage = nullptr;   // the selectors' 4N evaluations pass through here on their way to the lazy format
-  G16_HIP(hipMalloc(&d_stage, (size_t)N * 128));
+  // the selectors' 4N evaluations pass through d_T (allocated here, scratch of the proofs later) on their way to the
+  // lazy format
+  G16_HIP(hipMalloc(&P->d_T, (size_t)N * 128));
+  FrM* d_stage = P->d_T;
   for (int k = 0; k < 8; k++) {
     const uint8_t* src = k < 5 ? s[7 + k].p : s[12].p + (size_t)(k - 5) * polb;
     G16_HIP(hipMalloc(&P->d_pol[k], (size_t)N * 32));
@@ -611,7 +613,6 @@ int plonk_create_impl(const uint8_t* zkey, size_t len, int device, g16_plonk* P)
     G16_HIP(hipGetLastError());
   }
   G16_HIP(hipStreamSynchronize(st));
-  (void)hipFree(d_stage);
   // maps, zero padded to N
   for (int c = 0; c < 3; c++) {
     G16_HIP(hipMalloc(&P->d_map[c], (size_t)N * 4));
@@ -661,8 +662,7 @@ int plonk_create_impl(const uint8_t* zkey, size_t len, int device, g16_plonk* P)
   }
   // scratch
   const size_t n4 = (size_t)N * 4;
-  FrM** four[] = {&P->d_T, &P->d_Tz};
-  for (FrM** p : four) G16_HIP(hipMalloc(p, n4 * 32));
+  G16_HIP(hipMalloc(&P->d_Tz, n4 * 32));   // (d_T: above)
   F29** four_l[] = {&P->d_A4, &P->d_B4, &P->d_C4, &P->d_Z4, &P->d_pi4, &P->d_om4, &P->d_l1, &P->d_lazy, &P->d_lazy2};
   for (F29** p : four_l) G16_HIP(hipMalloc(p, n4 * sizeof(F29)));
   FrM** one[] = {&P->d_A, &P->d_B, &P->d_C, &P->d_Z, &P->d_tmpN, &P->d_tmpN2, &P->d_tmpN3, &P->d_tmpN4,

@@ -623,7 +623,12 @@ static napi_value js_plonk_prove(napi_env env, napi_callback_info info) {
     bool b = false;
     size_t bl = 0;
     void* bd;
-    if (napi_is_buffer(env, argv[2], &b) == napi_ok && b && napi_get_buffer_info(env, argv[2], &bd, &bl) == napi_ok && bl == 288) {
+    if (napi_is_buffer(env, argv[2], &b) == napi_ok && b) {
+      if (napi_get_buffer_info(env, argv[2], &bd, &bl) != napi_ok || bl != 288) {
+        free(j);
+        napi_throw_range_error(env, NULL, "plonkProve: blinding must be nine 32-byte scalars (288 bytes)");
+        return NULL;
+      }
       memcpy(j->blind, bd, 288);
       j->have_blind = 1;
     }
