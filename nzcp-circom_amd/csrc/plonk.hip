@@ -13,11 +13,11 @@
 //   witness   additions by dependency level (the setup's queue-order reduction makes a balanced tree: <= ~10 levels),
 //             A/B/C = w[map]
 //   round 1   3 x (iNTT N, blinding tweak, NTT 4N), 3 commitments
-//   round 2   grand product: per-lane chunks (batched inversion of the denominators, local prefix products), carries
-//             on the host, Z; iNTT N, NTT 4N, commitment
+//   round 2   grand product: per-lane chunks (batched inversion of the denominators, local prefix products), the chunk
+//             carries by one workgroup, Z; iNTT N, NTT 4N, commitment
 //   round 3   one elementwise kernel over the 4N domain (gate, permutation and L1 terms with the blinding parts tracked
 //             apart: T and Tz), 2 iNTT 4N, division by Z_H as a stride-N recurrence, 3 commitments
-//   round 4   evaluations at xi by chunked Horner (device) + carry combination (host), linearisation polynomial r
+//   round 4   evaluations at xi by chunked Horner + a one-workgroup carry combination, linearisation polynomial r
 //   round 5   opening polynomials by chunked synthetic division, 2 commitments
 // The public-input polynomial comes from an iNTT/NTT of the public signals, not from the zkey's Lagrange section
 // (which is not read: 513 public signals at N = 2^22 make it 344 GB).
@@ -361,6 +361,68 @@ __global__ __launch_bounds__(256) void k_divpol(const FrM* __restrict__ P, uint3
     r = fp_add(P[i], fp_mul(d, r));
   }
 }
+// The carries between chunks, on the device (one workgroup of 1024 lanes, up to 65 536 chunk values; first version:
+// copied to the host, combined there, copied back -- ~11 ms of a 113 ms proof).
+// E[c] = H[c] + m E[c + 1], E[nc] = 0: the chunk values of a Horner evaluation / synthetic division combined.
+__global__ __launch_bounds__(1024) void k_suffix_horner(const FrM* __restrict__ H, uint32_t nc, FrM m, FrM* __restrict__ E) {
+  __shared__ FrM sm[1024];
+  const uint32_t t = threadIdx.x;
+  const uint32_t B = (nc + 1023) / 1024;
+  const uint32_t lo = t * B < nc ? t * B : nc, hi = lo + B < nc ? lo + B : nc;
+  FrM r = fp_zero<FrParams>();
+  for (uint32_t i = hi; i-- > lo;) {
+    r = fp_add(H[i], fp_mul(m, r));
+    E[i] = r;
+  }
+  sm[t] = r;
+  FrM pw = fp_pow_u64(m, B);
+  __syncthreads();
+  for (uint32_t d = 1; d < 1024; d <<= 1) {
+    const FrM v = t + d < 1024 ? sm[t + d] : fp_zero<FrParams>();
+    __syncthreads();
+    sm[t] = fp_add(sm[t], fp_mul(pw, v));
+    pw = fp_sqr(pw);
+    __syncthreads();
+  }
+  const FrM carry = t + 1 < 1024 ? sm[t + 1] : fp_zero<FrParams>();
+  FrM q = m;
+  for (uint32_t i = hi; i-- > lo;) {
+    E[i] = fp_add(E[i], fp_mul(q, carry));
+    q = fp_mul(q, m);
+  }
+  if (t == 0) E[nc] = fp_zero<FrParams>();
+}
+// carry[c] = prod_{j < c} tot[j]; flag set when the product of all is not one
+__global__ __launch_bounds__(1024) void k_prefix_prod(const FrM* __restrict__ tot, uint32_t nc, FrM* __restrict__ carry,
+                                                       uint32_t* __restrict__ flag) {
+  __shared__ FrM sm[1024];
+  const uint32_t t = threadIdx.x;
+  const uint32_t B = (nc + 1023) / 1024;
+  const uint32_t lo = t * B < nc ? t * B : nc, hi = lo + B < nc ? lo + B : nc;
+  FrM r = fp_one<FrParams>();
+  for (uint32_t i = lo; i < hi; i++) {
+    carry[i] = r;
+    r = fp_mul(r, tot[i]);
+  }
+  sm[t] = r;
+  __syncthreads();
+  for (uint32_t d = 1; d < 1024; d <<= 1) {
+    const FrM v = t >= d ? sm[t - d] : fp_one<FrParams>();
+    __syncthreads();
+    sm[t] = fp_mul(sm[t], v);
+    __syncthreads();
+  }
+  const FrM c0 = t ? sm[t - 1] : fp_one<FrParams>();
+  for (uint32_t i = lo; i < hi; i++) carry[i] = fp_mul(carry[i], c0);
+  if (t == 1023 && !fp_eq(sm[1023], fp_one<FrParams>())) atomicOr(flag, 1u);
+}
+__global__ void k_flag_nonzero(const FrM* __restrict__ x, uint32_t* __restrict__ flag) {
+  if (threadIdx.x == 0 && blockIdx.x == 0 && !fp_is_zero(x[0])) atomicOr(flag, 1u);
+}
+__global__ void k_copy1(const FrM* __restrict__ src, FrM* __restrict__ dst) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) dst[0] = src[0];
+}
+
 struct R4Args { FrM coefz, coef_ab, ea, eb, ec, coefs3; };
 // pol_r[i] = coefz z[i] (+ coef_ab qm + ea ql + eb qr + ec qo + qc - coefs3 s3 for i < n), i < n + 3
 __global__ __launch_bounds__(256) void k_pol_r(const FrM* __restrict__ z, const FrM* __restrict__ qm, const FrM* __restrict__ ql,
@@ -450,11 +512,11 @@ struct g16_plonk {
   FrM *d_cA = nullptr, *d_cB = nullptr, *d_cC = nullptr, *d_cZ = nullptr;   // unblinded coefficients (the side stream pads them)
   FrM *d_pi_ev = nullptr, *d_pi_co = nullptr;
   FrM *d_r = nullptr, *d_wxi = nullptr, *d_q = nullptr;
-  FrM *d_tot = nullptr;                 // chunk totals / Horner partials
+  FrM *d_tot = nullptr, *d_tot2 = nullptr;   // chunk totals / Horner partials, and their combined carries
+  FrM* d_evals = nullptr;               // 8 evaluation results, read back once per round
   F29 *d_lazy = nullptr, *d_lazy2 = nullptr;   // 4N lazy elements each: the transforms' working vectors (T and Tz in round 3)
   Fr* d_scal = nullptr;                 // N + 6 standard-form MSM scalars
   uint32_t* d_bad = nullptr;
-  std::vector<FrM> h_tot;
   float last_ms[6] = {};
   std::mutex mu;
   ~g16_plonk() {
@@ -464,7 +526,7 @@ struct g16_plonk {
     for (auto p : d_pol) if (p) (void)hipFree(p);
     for (auto p : d_map) if (p) (void)hipFree(p);
     void* v[] = {d_add_s1, d_add_s2, d_add_order, d_add_f1, d_add_f2, d_om4, d_l1, d_wraw, d_w, d_A, d_B, d_C, d_Z, d_pa, d_pb, d_pc,
-                 d_pz, d_A4, d_B4, d_C4, d_Z4, d_T, d_Tz, d_pi4, d_tmpN, d_tmpN2, d_tmpN3, d_tmpN4, d_r, d_wxi, d_q, d_tot, d_lazy, d_lazy2, d_cA, d_cB, d_cC, d_cZ, d_pi_ev, d_pi_co,
+                 d_pz, d_A4, d_B4, d_C4, d_Z4, d_T, d_Tz, d_pi4, d_tmpN, d_tmpN2, d_tmpN3, d_tmpN4, d_r, d_wxi, d_q, d_tot, d_lazy, d_lazy2, d_cA, d_cB, d_cC, d_cZ, d_pi_ev, d_pi_co, d_tot2, d_evals,
                  d_scal, d_bad};
     for (void* p : v) if (p) (void)hipFree(p);
     if (ws) msm_workspace_destroy(ws);
@@ -674,8 +736,9 @@ int plonk_create_impl(const uint8_t* zkey, size_t len, int device, g16_plonk* P)
   G16_HIP(hipMalloc(&P->d_w, (size_t)P->nVars * 32));
   G16_HIP(hipMalloc(&P->d_scal, ((size_t)N + 8) * 32));
   G16_HIP(hipMalloc(&P->d_tot, (n4 / kChunk + 8) * 32));
+  G16_HIP(hipMalloc(&P->d_tot2, (n4 / kChunk + 8) * 32));
+  G16_HIP(hipMalloc(&P->d_evals, 8 * 32));
   G16_HIP(hipMalloc(&P->d_bad, 64));
-  P->h_tot.resize(n4 / kChunk + 8);
   // w_4N^i and the 4N evaluations of L1 = NTT(iNTT(e_0))
   k_powers<<<nblk(nblk(n4, kChunk)), 256, 0, st>>>(h_root((int)P->L + 2), (uint32_t)n4, P->d_T);
   k_to_lazy<<<nblk(n4), 256, 0, st>>>(P->d_T, P->d_om4, n4);
@@ -750,40 +813,32 @@ int commit3(g16_plonk* P, const FrM* const coefs[3], const uint32_t lens[3], G1A
   return rc;
 }
 
-// sum_i P[i] x^i over n device coefficients: chunked Horner on the device, the chunk values combined on the host
-int eval_pol(g16_plonk* P, const FrM* d_pol, uint32_t n, const FrM& x, FrM* out) {
+// sum_i P[i] x^i over n device coefficients -> d_evals[slot]: chunked Horner, the chunk values combined by one
+// workgroup (nothing leaves the device; read_evals fetches the slots of a round at once)
+int eval_pol_async(g16_plonk* P, const FrM* d_pol, uint32_t n, const FrM& x, int slot) {
   const uint32_t nc = (n + kHorner - 1) / kHorner;
   k_horner<<<nblk(nc), 256, 0, P->st>>>(d_pol, n, x, P->d_tot);
+  k_suffix_horner<<<1, 1024, 0, P->st>>>(P->d_tot, nc, h_pow(x, kHorner), P->d_tot2);
+  k_copy1<<<1, 1, 0, P->st>>>(P->d_tot2, P->d_evals + slot);
   G16_HIP(hipGetLastError());
-  G16_HIP(hipMemcpyAsync(P->h_tot.data(), P->d_tot, (size_t)nc * 32, hipMemcpyDeviceToHost, P->st));
+  return G16_OK;
+}
+int read_evals(g16_plonk* P, FrM* out, int count) {
+  G16_HIP(hipMemcpyAsync(out, P->d_evals, (size_t)count * 32, hipMemcpyDeviceToHost, P->st));
   G16_HIP(hipStreamSynchronize(P->st));
-  const FrM xc = h_pow(x, kHorner);
-  FrM r = fp_zero<FrParams>();
-  for (uint32_t c = nc; c-- > 0;) r = fp_add(fp_mul(r, xc), P->h_tot[c]);
-  *out = r;
   return G16_OK;
 }
 
-// res = (P - P(d)) / (X - d) for a P with P(d) == 0 (n coefficients; res has n entries, the top one zero)
-int div_pol1(g16_plonk* P, const FrM* d_pol, uint32_t n, const FrM& d, FrM* d_res) {
+// res = P / (X - d) for a P with P(d) == 0 (n coefficients; res has n entries, the top one zero); d_bad[flag] is set
+// when the remainder is not zero
+int div_pol1(g16_plonk* P, const FrM* d_pol, uint32_t n, const FrM& d, FrM* d_res, int flag) {
   const uint32_t nc = (n + kHorner - 1) / kHorner;
   k_horner<<<nblk(nc), 256, 0, P->st>>>(d_pol, n, d, P->d_tot);
+  // E[c] = sum_{j >= lo_c} P[j] d^(j - lo_c) = H[c] + d^256 E[c + 1]  (only the last chunk is short, and E beyond it is 0)
+  k_suffix_horner<<<1, 1024, 0, P->st>>>(P->d_tot, nc, h_pow(d, kHorner), P->d_tot2);
+  k_flag_nonzero<<<1, 1, 0, P->st>>>(P->d_tot2, P->d_bad + flag);
+  k_divpol<<<nblk(nc), 256, 0, P->st>>>(d_pol, n, d, P->d_tot2, d_res);
   G16_HIP(hipGetLastError());
-  G16_HIP(hipMemcpyAsync(P->h_tot.data(), P->d_tot, (size_t)nc * 32, hipMemcpyDeviceToHost, P->st));
-  G16_HIP(hipStreamSynchronize(P->st));
-  // E[c] = sum_{j >= lo_c} P[j] d^(j - lo_c) = H[c] + d^len_c E[c + 1]; every chunk but the last is full
-  std::vector<FrM> E(nc + 1);
-  E[nc] = fp_zero<FrParams>();
-  const FrM dc = h_pow(d, kHorner);
-  for (uint32_t c = nc; c-- > 0;) {
-    const uint32_t lenc = c + 1 == nc ? n - c * kHorner : kHorner;
-    E[c] = fp_add(P->h_tot[c], fp_mul(lenc == kHorner ? dc : h_pow(d, lenc), E[c + 1]));
-  }
-  if (!fp_is_zero(E[0])) { set_error("Polinomial does not divide"); return G16_E_STATE; }
-  G16_HIP(hipMemcpyAsync(P->d_tot, E.data(), (size_t)(nc + 1) * 32, hipMemcpyHostToDevice, P->st));
-  k_divpol<<<nblk(nc), 256, 0, P->st>>>(d_pol, n, d, P->d_tot, d_res);
-  G16_HIP(hipGetLastError());
-  G16_HIP(hipStreamSynchronize(P->st));   // (E is a host temporary)
   return G16_OK;
 }
 
@@ -853,6 +908,7 @@ int plonk_prove_impl(g16_plonk* P, const uint8_t* wtns, size_t wlen, const uint8
     tprev = now;
   };
   // ---- witness: first element zeroed ("not used in plonk"), additions level by level, A/B/C
+  G16_HIP(hipMemsetAsync(P->d_bad, 0, 32, st));
   G16_HIP(hipMemcpyAsync(P->d_wraw, s[2].p, (size_t)P->nBase * 32, hipMemcpyHostToDevice, st));
   k_to_mont<<<nblk(P->nBase), 256, 0, st>>>(P->d_wraw, P->d_w, P->nBase, 1u);
   for (size_t l = 0; l + 1 < P->level_start.size(); l++) {
@@ -916,20 +972,9 @@ int plonk_prove_impl(g16_plonk* P, const uint8_t* wtns, size_t wlen, const uint8
     // num -> d_tmpN (ratios), den -> d_tmpN2, pre -> d_tmpN3, lp -> d_tmpN4
     k_z_local<<<nblk(nc), 256, 0, st>>>(P->d_A, P->d_B, P->d_C, P->d_ext[5], P->d_ext[6], P->d_ext[7], a, N, P->d_tmpN, P->d_tmpN2,
                                         P->d_tmpN3, P->d_tmpN4, P->d_tot);
+    k_prefix_prod<<<1, 1024, 0, st>>>(P->d_tot, nc, P->d_tot2, P->d_bad + 2);   // "Copy constraints does not match": read in round 3
+    k_z_apply<<<nblk(N), 256, 0, st>>>(P->d_tmpN4, P->d_tot2, N, P->d_Z);
     G16_HIP(hipGetLastError());
-    G16_HIP(hipMemcpyAsync(P->h_tot.data(), P->d_tot, (size_t)nc * 32, hipMemcpyDeviceToHost, st));
-    G16_HIP(hipStreamSynchronize(st));
-    std::vector<FrM> carry(nc);
-    FrM run = fp_one<FrParams>();
-    for (uint32_t c = 0; c < nc; c++) {
-      carry[c] = run;
-      run = fp_mul(run, P->h_tot[c]);
-    }
-    if (!fp_eq(run, fp_one<FrParams>())) { set_error("Copy constraints does not match"); return G16_E_STATE; }
-    G16_HIP(hipMemcpyAsync(P->d_tot, carry.data(), (size_t)nc * 32, hipMemcpyHostToDevice, st));
-    k_z_apply<<<nblk(N), 256, 0, st>>>(P->d_tmpN4, P->d_tot, N, P->d_Z);
-    G16_HIP(hipGetLastError());
-    G16_HIP(hipStreamSynchronize(st));
   }
   Pz pzz{{b[9], b[8], b[7]}, 3};
   if ((rc = to_pol(P->d_Z, pzz, P->d_pz, P->d_cZ))) return rc;
@@ -962,12 +1007,12 @@ int plonk_prove_impl(g16_plonk* P, const uint8_t* wtns, size_t wlen, const uint8
     G16_HIP(hipGetLastError());
     if ((rc = ifft_from_lazy(P->ntt_4n, P->d_lazy, P->d_T, st))) return rc;
     if ((rc = ifft_from_lazy(P->ntt_4n, P->d_lazy2, P->d_Tz, st))) return rc;
-    G16_HIP(hipMemsetAsync(P->d_bad, 0, 8, st));
     k_div_zh<<<nblk(N), 256, 0, st>>>(P->d_T, P->d_Tz, N, P->d_bad);
     G16_HIP(hipGetLastError());
-    uint32_t bad[2] = {0, 0};
-    G16_HIP(hipMemcpyAsync(bad, P->d_bad, 8, hipMemcpyDeviceToHost, st));
+    uint32_t bad[3] = {0, 0, 0};
+    G16_HIP(hipMemcpyAsync(bad, P->d_bad, 12, hipMemcpyDeviceToHost, st));
     G16_HIP(hipStreamSynchronize(st));
+    if (bad[2]) { set_error("Copy constraints does not match"); return G16_E_STATE; }
     if (bad[0]) { set_error("T Polynomial is not divisible"); return G16_E_STATE; }
     if (bad[1]) { set_error("Tz Polynomial is not well calculated"); return G16_E_STATE; }
   }
@@ -985,14 +1030,19 @@ int plonk_prove_impl(g16_plonk* P, const uint8_t* wtns, size_t wlen, const uint8
   put_g1_be(tr, pr->T3);
   const FrM xi = hash_to_fr(tr);
   FrM et;
-  if ((rc = eval_pol(P, P->d_pa, N + 2, xi, &pr->ea))) return rc;
-  if ((rc = eval_pol(P, P->d_pb, N + 2, xi, &pr->eb))) return rc;
-  if ((rc = eval_pol(P, P->d_pc, N + 2, xi, &pr->ec))) return rc;
-  if ((rc = eval_pol(P, P->d_pol[5], N, xi, &pr->es1))) return rc;
-  if ((rc = eval_pol(P, P->d_pol[6], N, xi, &pr->es2))) return rc;
-  if ((rc = eval_pol(P, P->d_T, 3 * N + 6, xi, &et))) return rc;
   const FrM xiw = fp_mul(xi, P->w1);
-  if ((rc = eval_pol(P, P->d_pz, N + 3, xiw, &pr->ezw))) return rc;
+  {
+    if ((rc = eval_pol_async(P, P->d_pa, N + 2, xi, 0))) return rc;
+    if ((rc = eval_pol_async(P, P->d_pb, N + 2, xi, 1))) return rc;
+    if ((rc = eval_pol_async(P, P->d_pc, N + 2, xi, 2))) return rc;
+    if ((rc = eval_pol_async(P, P->d_pol[5], N, xi, 3))) return rc;
+    if ((rc = eval_pol_async(P, P->d_pol[6], N, xi, 4))) return rc;
+    if ((rc = eval_pol_async(P, P->d_T, 3 * N + 6, xi, 5))) return rc;
+    if ((rc = eval_pol_async(P, P->d_pz, N + 3, xiw, 6))) return rc;
+    FrM evs[7];
+    if ((rc = read_evals(P, evs, 7))) return rc;
+    pr->ea = evs[0]; pr->eb = evs[1]; pr->ec = evs[2]; pr->es1 = evs[3]; pr->es2 = evs[4]; et = evs[5]; pr->ezw = evs[6];
+  }
   FrM xim = xi;
   for (uint32_t i = 0; i < P->L; i++) xim = fp_sqr(xim);
   {
@@ -1010,7 +1060,8 @@ int plonk_prove_impl(g16_plonk* P, const uint8_t* wtns, size_t wlen, const uint8
                                          P->d_r);
     G16_HIP(hipGetLastError());
   }
-  if ((rc = eval_pol(P, P->d_r, N + 3, xi, &pr->er))) return rc;
+  if ((rc = eval_pol_async(P, P->d_r, N + 3, xi, 0))) return rc;
+  if ((rc = read_evals(P, &pr->er, 1))) return rc;
   lap(3);
   // ---- round 5
   tr.clear();
@@ -1027,15 +1078,21 @@ int plonk_prove_impl(g16_plonk* P, const uint8_t* wtns, size_t wlen, const uint8
                    fp_add(fp_mul(a5.v[5], pr->es1), fp_mul(a5.v[6], pr->es2)))))));
   k_pol_wxi<<<nblk(N + 6), 256, 0, st>>>(P->d_T, P->d_r, P->d_pa, P->d_pb, P->d_pc, P->d_pol[5], P->d_pol[6], a5, N, P->d_wxi);
   G16_HIP(hipGetLastError());
-  if ((rc = div_pol1(P, P->d_wxi, N + 6, xi, P->d_q))) return rc;
+  if ((rc = div_pol1(P, P->d_wxi, N + 6, xi, P->d_q, 3))) return rc;
   G16_HIP(hipMemcpyAsync(P->d_r, P->d_pz, ((size_t)N + 3) * 32, hipMemcpyDeviceToDevice, st));   // (r is spent)
   k_sub0<<<1, 1, 0, st>>>(P->d_r, pr->ezw);
-  if ((rc = div_pol1(P, P->d_r, N + 3, xiw, P->d_wxi))) return rc;
+  if ((rc = div_pol1(P, P->d_r, N + 3, xiw, P->d_wxi, 4))) return rc;
   {
     const FrM* cf[3] = {P->d_q, P->d_wxi, nullptr};
     const uint32_t ln[3] = {N + 6, N + 3, 0};
     G1Affine* o[3] = {&pr->Wxi, &pr->Wxiw, nullptr};
     if ((rc = commit3(P, cf, ln, o, 2))) return rc;
+  }
+  {
+    uint32_t bad[2] = {0, 0};
+    G16_HIP(hipMemcpyAsync(bad, P->d_bad + 3, 8, hipMemcpyDeviceToHost, st));
+    G16_HIP(hipStreamSynchronize(st));
+    if (bad[0] || bad[1]) { set_error("Polinomial does not divide"); return G16_E_STATE; }
   }
   lap(4);
   P->last_ms[5] = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - tstart).count();
