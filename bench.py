@@ -238,13 +238,33 @@ def plonk_leg(amd, dev, log, steps=3):
     rounds = prover.timings()
     proof, pub = prover.prove(out["wtns"])
     ok = pk.verify(vk, [int(x) for x in pub], pk.proof_from_obj(proof))
+    # ... and by the device PLONK verifier (csrc/verify_plonk.hip): 256 copies, one with a changed public signal
+
+    def g1j(P):
+        return ["0", "1", "0"] if P is None else [str(P[0]), str(P[1]), "1"]
+    vkj = {"protocol": "plonk", "nPublic": vk["nPublic"], "power": vk["power"], "k1": vk["k1"], "k2": vk["k2"],
+           "X_2": [[str(vk["X_2"][0][0]), str(vk["X_2"][0][1])], [str(vk["X_2"][1][0]), str(vk["X_2"][1][1])], ["1", "0"]]}
+    for k_ in ("Qm", "Ql", "Qr", "Qo", "Qc", "S1", "S2", "S3"):
+        vkj[k_] = g1j(vk[k_])
+    pver = amd.PlonkVerifier(vkj, device=dev)
+    bad_pub = list(pub)
+    bad_pub[0] = str(1 - int(bad_pub[0])) if bad_pub[0] in ("0", "1") else str(int(bad_pub[0]) + 1)
+    items = [(pub, proof)] * 255 + [(bad_pub, proof)]
+    pver.verify_batch(items[:8])
+    tv = time.perf_counter()
+    verdicts = pver.verify_batch(items)
+    tv = time.perf_counter() - tv
+    pver.close()
+    dev_ok = verdicts == [True] * 255 + [False]
     res = {"proofs_per_sec": round(1 / min(ts), 3), "ms_per_proof": round(min(ts) * 1e3, 2),
+           "device_verifier": {"proofs": 256, "ms": round(tv * 1e3, 1), "verdicts_as_expected": bool(dev_ok)},
            "workload": f"nzcp_exampleTest as PLONK: domain 2^{prover.domain_size.bit_length() - 1}, {prover.n_constraints} gates, "
                        f"{prover.n_additions} addition gates, {prover.n_public} public signals",
            "rounds_ms": rounds, "verified_by_oracle_kzg": bool(ok), "prepare_s": round(time.time() - t0, 1)}
     prover.close()
     log(f"plonk: {res['ms_per_proof']} ms per proof, verified {ok}")
     assert ok, "PLONK proof rejected by the oracle verifier"
+    assert dev_ok, "device PLONK verifier: unexpected verdicts"
     return res
 
 

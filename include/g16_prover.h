@@ -326,6 +326,17 @@ int g16_plonk_setup_ptau(const uint8_t* r1cs, size_t r1cs_len, const uint8_t* pt
  * file is 4.6 GB, the key it yields 5.8 GB without the Lagrange section */
 int g16_plonk_setup_files(const char* r1cs_path, const char* ptau_path, const char* zkey_path, int device, int with_lagrange);
 
+/* PLONK batch verifier on the device: [EXT] snarkjs 0.4.12 plonk_verify.js `plonk.verify(vk, publicSignals, proof)` for
+ * many proofs against one key, one verdict per proof (transcript and scalar arithmetic on host threads, the twenty
+ * scalar multiplications, two Miller loops and the final exponentiation of every proof on the device).
+ * vkey (712 bytes, what verification_key.json holds, standard-form little-endian): power u32 | nPublic u32 | k1 (32) |
+ * k2 (32) | Qm Ql Qr Qo Qc S1 S2 S3 (64 each: x | y) | X_2 (128: x.c0 | x.c1 | y.c0 | y.c1).
+ * proofs: g16_plonk_proof as g16_plonk_prove writes them; pubs: count * nPublic * 32 bytes.  ok[i] = 1 / 0. */
+typedef struct g16_plonk_verifier g16_plonk_verifier;
+int g16_plonk_verifier_create(const uint8_t* vkey, size_t vkey_len, int device, g16_plonk_verifier** out);
+int g16_plonk_verify_batch(g16_plonk_verifier* v, const g16_plonk_proof* proofs, const uint8_t* pubs, size_t count, uint8_t* ok);
+void g16_plonk_verifier_destroy(g16_plonk_verifier* v);
+
 #ifdef __cplusplus
 }
 #endif

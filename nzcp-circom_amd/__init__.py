@@ -66,7 +66,8 @@ EXPORTS = ["g16_create", "g16_prove", "g16_prove_batch", "g16_stage_witness", "g
            "g16_multi_create", "g16_multi_prove", "g16_multi_get_info", "g16_multi_destroy",
            "g16_nzcp_gadget", "g16_nzcp_circuit_setup", "g16_setup_device",
            "g16_verifier_create", "g16_verify_batch", "g16_verifier_timings", "g16_verifier_destroy", "g16_pairing_op",
-           "g16_plonk_create", "g16_plonk_prove", "g16_plonk_get_info", "g16_plonk_destroy", "g16_plonk_setup", "g16_plonk_timings", "g16_plonk_setup_ptau", "g16_plonk_setup_files"]
+           "g16_plonk_create", "g16_plonk_prove", "g16_plonk_get_info", "g16_plonk_destroy", "g16_plonk_setup", "g16_plonk_timings", "g16_plonk_setup_ptau", "g16_plonk_setup_files",
+           "g16_plonk_verifier_create", "g16_plonk_verify_batch", "g16_plonk_verifier_destroy"]
 
 
 def load():
@@ -132,6 +133,10 @@ def load():
     lib.g16_plonk_destroy.restype = None
     lib.g16_plonk_timings.argtypes = [vp, C.POINTER(C.c_float)]
     lib.g16_plonk_setup.argtypes = [C.c_char_p, sz, C.c_uint64, C.c_int, C.c_int, C.POINTER(vp), C.POINTER(sz)]
+    lib.g16_plonk_verifier_create.argtypes = [C.c_char_p, sz, C.c_int, C.POINTER(vp)]
+    lib.g16_plonk_verify_batch.argtypes = [vp, C.c_char_p, C.c_char_p, sz, C.c_char_p]
+    lib.g16_plonk_verifier_destroy.argtypes = [vp]
+    lib.g16_plonk_verifier_destroy.restype = None
     lib.g16_plonk_setup_files.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.c_int, C.c_int]
     lib.g16_plonk_setup_ptau.argtypes = [C.c_char_p, sz, C.c_char_p, sz, C.c_int, C.c_int, C.POINTER(vp), C.POINTER(sz)]
     lib.g16_r1cs_setup.argtypes = [C.c_char_p, sz, C.c_uint64, C.c_int, C.POINTER(vp), C.POINTER(sz), C.POINTER(vp), C.POINTER(sz)]
@@ -636,6 +641,52 @@ class PlonkProver:
     def close(self):
         if getattr(self, "_h", None) and self._h.value:
             load().g16_plonk_destroy(self._h)
+            self._h = C.c_void_p()
+
+    __del__ = close
+
+
+def plonk_proof_from_obj(o):
+    """proof.json object of `plonk prove` -> g16_plonk_proof bytes (standard LE)."""
+    def g1(t):
+        return bytes(64) if str(t[2]) == "0" else _le32(t[0]) + _le32(t[1])
+    return (b"".join(g1(o[k]) for k in _PLONK_G1) + b"".join(_le32(o[k]) for k in _PLONK_EV) + g1(o["Wxi"]) + g1(o["Wxiw"]))
+
+
+def plonk_vkey_bytes(vk):
+    """verification_key.json object of a PLONK key -> the C ABI's 712-byte image."""
+    def g1(t):
+        return bytes(64) if str(t[2]) == "0" else _le32(t[0]) + _le32(t[1])
+    x2 = vk["X_2"]
+    return (int(vk["power"]).to_bytes(4, "little") + int(vk["nPublic"]).to_bytes(4, "little") + _le32(vk["k1"]) + _le32(vk["k2"]) +
+            b"".join(g1(vk[k]) for k in ("Qm", "Ql", "Qr", "Qo", "Qc", "S1", "S2", "S3")) +
+            _le32(x2[0][0]) + _le32(x2[0][1]) + _le32(x2[1][0]) + _le32(x2[1][1]))
+
+
+class PlonkVerifier:
+    """snarkjs `plonk.verify(vk, publicSignals, proof)` for batches: one verdict per proof."""
+
+    def __init__(self, vk, device=0):
+        self.n_public = int(vk["nPublic"])
+        b = plonk_vkey_bytes(vk)
+        self._h = C.c_void_p()
+        _check(load().g16_plonk_verifier_create(b, len(b), device, C.byref(self._h)))
+
+    def verify_batch(self, items):
+        """items: [(public_signals, proof_obj)] -> list of bools."""
+        short = [len(ps) != self.n_public for ps, _ in items]
+        pr = b"".join(plonk_proof_from_obj(p) for _, p in items)
+        pub = b"".join(b"".join(_le32(x) for x in (ps if not s else [0] * self.n_public)) for (ps, _), s in zip(items, short))
+        ok = C.create_string_buffer(max(1, len(items)))
+        _check(load().g16_plonk_verify_batch(self._h, pr, pub, len(items), ok))
+        return [ok.raw[i] != 0 and not short[i] for i in range(len(items))]
+
+    def verify(self, public_signals, proof):
+        return self.verify_batch([(public_signals, proof)])[0]
+
+    def close(self):
+        if getattr(self, "_h", None) and self._h.value:
+            load().g16_plonk_verifier_destroy(self._h)
             self._h = C.c_void_p()
 
     __del__ = close

@@ -54,7 +54,7 @@ using F2 = Fq2Ops;
 // (inlined everywhere, the verifier's translation unit was ~2 M instructions and took a quarter of an hour to
 // compile; the call costs a few dozen cycles per 1.6 k-instruction body).  The Fq12 operations are calls as well.
 #if defined(__HIPCC__)
-#define G16_F12_FN __host__ __device__ __noinline__
+#define G16_F12_FN static __host__ __device__ __noinline__   // (internal linkage: two translation units include this header)
 #else
 #define G16_F12_FN inline
 #endif

@@ -360,15 +360,22 @@ static napi_value js_destroy(napi_env env, napi_callback_info info) {
 
 /* ------------------------------------------------------------------ verifier (g16_verifier_*): snarkjs groth16.verify */
 typedef struct {
-  g16_verifier* v;
+  g16_verifier* v;            /* Groth16 ... */
+  g16_plonk_verifier* pv;     /* ... or PLONK (exactly one of the two is set) */
   uint32_t n_public;
   uint32_t inflight;
   int closing;
 } vhandle_t;
+static void vhandle_release(vhandle_t* h) {
+  if (h->v) g16_verifier_destroy(h->v);
+  if (h->pv) g16_plonk_verifier_destroy(h->pv);
+  h->v = NULL;
+  h->pv = NULL;
+}
 
 static void vhandle_finalize(napi_env env, void* data, void* hint) {
   vhandle_t* h = (vhandle_t*)data;
-  if (h->v) g16_verifier_destroy(h->v);
+  vhandle_release(h);
   free(h);
 }
 
@@ -378,15 +385,23 @@ typedef struct {
   napi_ref refs[3];
   int nrefs;
   int kind;                 /* 0 = create, 1 = verify */
+  int plonk;                /* the PLONK verifier (vkey = the 712-byte image, proofs of 832 bytes) */
   const uint8_t* vkey; size_t vkey_len; uint32_t n_public; int montgomery, device; g16_verifier* created;
+  g16_plonk_verifier* created_pv;
   vhandle_t* h; const uint8_t* proofs; const uint8_t* pubs; size_t count; uint8_t* ok;
   int rc; char err[512];
 } vjob_t;
 
 static void vjob_execute(napi_env env, void* data) {
   vjob_t* j = (vjob_t*)data;
-  if (j->kind == 0) j->rc = g16_verifier_create(j->vkey, j->vkey_len, j->n_public, j->montgomery, j->device, &j->created);
-  else j->rc = g16_verify_batch(j->h->v, (const g16_proof*)j->proofs, j->pubs, j->count, j->ok);
+  if (j->plonk) {
+    if (j->kind == 0) j->rc = g16_plonk_verifier_create(j->vkey, j->vkey_len, j->device, &j->created_pv);
+    else j->rc = g16_plonk_verify_batch(j->h->pv, (const g16_plonk_proof*)j->proofs, j->pubs, j->count, j->ok);
+  } else if (j->kind == 0) {
+    j->rc = g16_verifier_create(j->vkey, j->vkey_len, j->n_public, j->montgomery, j->device, &j->created);
+  } else {
+    j->rc = g16_verify_batch(j->h->v, (const g16_proof*)j->proofs, j->pubs, j->count, j->ok);
+  }
   if (j->rc) {
     strncpy(j->err, g16_last_error(), sizeof(j->err) - 1);
     j->err[sizeof(j->err) - 1] = 0;
@@ -404,6 +419,7 @@ static void vjob_complete(napi_env env, napi_status status, void* data) {
   } else if (j->kind == 0) {
     vhandle_t* h = (vhandle_t*)calloc(1, sizeof(vhandle_t));
     h->v = j->created;
+    h->pv = j->created_pv;
     h->n_public = j->n_public;
     napi_create_external(env, h, vhandle_finalize, NULL, &result);
     napi_resolve_deferred(env, j->deferred, result);
@@ -414,7 +430,7 @@ static void vjob_complete(napi_env env, napi_status status, void* data) {
   }
   if (j->h) {
     j->h->inflight--;
-    if (j->h->closing && j->h->inflight == 0 && j->h->v) { g16_verifier_destroy(j->h->v); j->h->v = NULL; }
+    if (j->h->closing && j->h->inflight == 0) vhandle_release(j->h);
   }
   for (int i = 0; i < j->nrefs; i++) napi_delete_reference(env, j->refs[i]);
   napi_delete_async_work(env, j->work);
@@ -432,17 +448,19 @@ static napi_value queue_vjob(napi_env env, vjob_t* j, const char* name) {
 }
 
 static napi_value js_create_verifier(napi_env env, napi_callback_info info) {
-  size_t argc = 4;
-  napi_value argv[4];
+  size_t argc = 5;
+  napi_value argv[5];
   bool isbuf = false;
   NAPI_OK(napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
   if (argc < 4 || napi_is_buffer(env, argv[0], &isbuf) != napi_ok || !isbuf) {
-    napi_throw_type_error(env, NULL, "createVerifier(vkey: Buffer, nPublic, montgomery, device)");
+    napi_throw_type_error(env, NULL, "createVerifier(vkey: Buffer, nPublic, montgomery, device[, plonk])");
     return NULL;
   }
   vjob_t* j = (vjob_t*)calloc(1, sizeof(vjob_t));
   void* data;
-  int32_t mont = 0, dev = 0;
+  int32_t mont = 0, dev = 0, pl = 0;
+  if (argc > 4) napi_get_value_int32(env, argv[4], &pl);
+  j->plonk = pl != 0;
   NAPI_OK(napi_get_buffer_info(env, argv[0], &data, &j->vkey_len));
   j->vkey = (const uint8_t*)data;
   NAPI_OK(napi_get_value_uint32(env, argv[1], &j->n_public));
@@ -460,7 +478,7 @@ static napi_value js_verify_batch(napi_env env, napi_callback_info info) {
   vhandle_t* h = NULL;
   bool b1 = false, b2 = false;
   NAPI_OK(napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
-  if (argc < 3 || napi_get_value_external(env, argv[0], (void**)&h) != napi_ok || !h || !h->v || h->closing ||
+  if (argc < 3 || napi_get_value_external(env, argv[0], (void**)&h) != napi_ok || !h || (!h->v && !h->pv) || h->closing ||
       napi_is_buffer(env, argv[1], &b1) != napi_ok || !b1 || napi_is_buffer(env, argv[2], &b2) != napi_ok || !b2) {
     napi_throw_type_error(env, NULL, "verifyBatch(vhandle, proofs: Buffer, pubs: Buffer)");
     return NULL;
@@ -469,16 +487,18 @@ static napi_value js_verify_batch(napi_env env, napi_callback_info info) {
   size_t plen, ulen;
   NAPI_OK(napi_get_buffer_info(env, argv[1], &pd, &plen));
   NAPI_OK(napi_get_buffer_info(env, argv[2], &ud, &ulen));
-  if (plen % sizeof(g16_proof) || ulen != (plen / sizeof(g16_proof)) * (size_t)h->n_public * 32) {
-    napi_throw_range_error(env, NULL, "verifyBatch: proofs must be count*256 bytes and pubs count*nPublic*32 bytes");
+  const size_t psz = h->pv ? sizeof(g16_plonk_proof) : sizeof(g16_proof);
+  if (plen % psz || ulen != (plen / psz) * (size_t)h->n_public * 32) {
+    napi_throw_range_error(env, NULL, "verifyBatch: proofs must be count*256 (groth16) / count*832 (plonk) bytes and pubs count*nPublic*32 bytes");
     return NULL;
   }
   vjob_t* j = (vjob_t*)calloc(1, sizeof(vjob_t));
   j->kind = 1;
+  j->plonk = h->pv != NULL;
   j->h = h;
   j->proofs = (const uint8_t*)pd;
   j->pubs = (const uint8_t*)ud;
-  j->count = plen / sizeof(g16_proof);
+  j->count = plen / psz;
   j->ok = (uint8_t*)calloc(j->count ? j->count : 1, 1);
   h->inflight++;
   NAPI_OK(napi_create_reference(env, argv[0], 1, &j->refs[j->nrefs++]));
@@ -492,9 +512,9 @@ static napi_value js_destroy_verifier(napi_env env, napi_callback_info info) {
   napi_value argv[1];
   vhandle_t* h = NULL;
   NAPI_OK(napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
-  if (argc >= 1 && napi_get_value_external(env, argv[0], (void**)&h) == napi_ok && h && h->v) {
+  if (argc >= 1 && napi_get_value_external(env, argv[0], (void**)&h) == napi_ok && h && (h->v || h->pv)) {
     h->closing = 1;
-    if (h->inflight == 0) { g16_verifier_destroy(h->v); h->v = NULL; }
+    if (h->inflight == 0) vhandle_release(h);
   }
   return NULL;
 }

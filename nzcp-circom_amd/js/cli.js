@@ -32,6 +32,15 @@ async function main(argv) {
     return;
   }
   if (a[0] === "groth16") a = a.slice(1);
+  if (a[0] === "plonk" && a[1] === "verify") {   // snarkjs plonk verify <verification_key.json> <public.json> <proof.json>
+    const { plonk } = require("./index.js");
+    const [vk = "verification_key.json", pub = "public.json", proof = "proof.json"] = a.slice(2).filter((x) => !x.startsWith("--"));
+    const ok = await plonk.verify(JSON.parse(fs.readFileSync(vk, "utf-8")), JSON.parse(fs.readFileSync(pub, "utf-8")),
+      JSON.parse(fs.readFileSync(proof, "utf-8")));
+    if (!ok) throw new Error("Invalid proof");
+    console.log("[INFO]  snarkJS: OK!");
+    return;
+  }
   if (a[0] === "verify") {
     const pos = a.slice(1).filter((x) => !x.startsWith("--"));
     const di = a.indexOf("--device");

@@ -207,7 +207,47 @@ class PlonkProver {
     return this._busy;
   }
 }
+// verification_key.json / proof.json of PLONK -> the C ABI images (g16_plonk_verifier_create, g16_plonk_proof)
+function plonkVkeyBytes(vk) {
+  if (!vk || vk.protocol !== "plonk") throw new Error("verification key: not a plonk key");
+  const head = Buffer.alloc(8);
+  head.writeUInt32LE(Number(vk.power), 0);
+  head.writeUInt32LE(Number(vk.nPublic), 4);
+  return Buffer.concat([head, le32(vk.k1), le32(vk.k2), ...["Qm", "Ql", "Qr", "Qo", "Qc", "S1", "S2", "S3"].map((k) => g1Bytes(vk[k])),
+    g2Bytes(vk.X_2)]);
+}
+function plonkProofBytes(p) {
+  return Buffer.concat([...PLONK_G1.map((k) => g1Bytes(p[k])), ...PLONK_EV.map((k) => le32(p[k])), g1Bytes(p.Wxi), g1Bytes(p.Wxiw)]);
+}
+class PlonkVerifier {
+  constructor(handle, nPublic) { this._h = handle; this.nPublic = nPublic; }
+  async verifyBatch(items) {
+    if (!this._h) throw new Error("verifier is closed");
+    const short = items.map((it) => it.publicSignals.length !== this.nPublic);
+    const proofs = Buffer.concat(items.map((it) => plonkProofBytes(it.proof)));
+    const pubs = Buffer.concat(items.map((it, i) => (short[i] ? Buffer.alloc(this.nPublic * 32)
+      : Buffer.concat(it.publicSignals.map(le32)))));
+    const ok = await native().verifyBatch(this._h, proofs, pubs);
+    return items.map((_, i) => !short[i] && ok[i] !== 0);
+  }
+  async verify(publicSignals, proof) { return (await this.verifyBatch([{ publicSignals, proof }]))[0]; }
+  close() { if (this._h) { native().destroyVerifier(this._h); this._h = null; } }
+}
+
 const plonk = {
+  // snarkjs: plonk.verify(vk_verifier, publicSignals, proof[, logger]) -> boolean
+  async verify(vk, publicSignals, proof, opts = {}) {
+    const v = await plonk.createVerifier(vk, opts && typeof opts.debug === "function" ? {} : opts);
+    try {
+      return await v.verify(publicSignals, proof);
+    } finally {
+      v.close();
+    }
+  },
+  async createVerifier(vk, opts = {}) {
+    const h = await native().createVerifier(plonkVkeyBytes(vk), Number(vk.nPublic), 0, opts.device | 0, 1);
+    return new PlonkVerifier(h, Number(vk.nPublic));
+  },
   // snarkjs: plonk.prove(zkeyFileName, witnessFileName[, logger]) -> {proof, publicSignals}
   async prove(zkey, wtns, opts = {}) {
     if (opts && typeof opts.debug === "function") opts = {};

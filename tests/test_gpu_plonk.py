@@ -157,3 +157,74 @@ def test_setup_from_a_ptau_file_equals_oracle(amd):
     with pytest.raises(amd.G16Error) as e:
         amd.plonk_setup_ptau(r1cs, ptau[:500], device=0)
     assert "Invalid File format" in str(e.value)
+
+
+def _vk_json(zk):
+    """verification_key.json of a PLONK key, as snarkjs writes it (decimal strings)."""
+    def g1(P):
+        return ["0", "1", "0"] if P is None else [str(P[0]), str(P[1]), "1"]
+    X2 = zk["X_2"]
+    vk = {"protocol": "plonk", "curve": "bn128", "nPublic": zk["nPublic"], "power": zk["power"], "k1": str(zk["k1"]), "k2": str(zk["k2"])}
+    for k in ("Qm", "Ql", "Qr", "Qo", "Qc", "S1", "S2", "S3"):
+        vk[k] = g1(zk[k])
+    vk["X_2"] = [[str(X2[0][0]), str(X2[0][1])], [str(X2[1][0]), str(X2[1][1])], ["1", "0"]]
+    vk["w"] = str(b.fr_root(zk["power"]))
+    return vk
+
+
+@pytest.mark.parametrize("n,p,m,seed", [(60, 5, 40, 3), (700, 513, 150, 4)])
+def test_plonk_verifier_verdicts_equal_oracle(amd, n, p, m, seed):
+    """`snarkjs plonk verify` on the device (csrc/verify_plonk.hip): every verdict -- valid proofs, a wrong public
+    signal, tampered evaluations and commitments, a point off the curve, a non-canonical coordinate, too few public
+    signals -- equals oracle/plonk.py::verify's."""
+    import copy
+    rows, w = synth.make(n, p, m, seed)
+    zk = pk.setup(n, p, rows, tau=0xfeed + seed)
+    vk = pk.vkey(zk)
+    rng = synth.Xoshiro(seed + 3)
+    proofs = []
+    for k in range(3):
+        wk = w if k == 0 else synth.make(n, p, m, seed, 500 + k)[1]
+        pr, pub = pk.prove(zk, wk, {i: rng.rand_fr() for i in range(1, 10)})
+        proofs.append((pub, pr))
+    cases = [([str(x) for x in pub], pk.proof_obj(pr)) for pub, pr in proofs]
+    pub0, pr0 = cases[0]
+    bad = list(pub0)
+    bad[p - 1] = str((int(bad[p - 1]) + 1) % b.R)
+    cases.append((bad, pr0))
+    for key in ("eval_a", "eval_s2", "eval_zw", "eval_r"):
+        t = copy.deepcopy(pr0)
+        t[key] = str((int(t[key]) + 1) % b.R)
+        cases.append((pub0, t))
+    for key in ("A", "Z", "T2", "Wxi", "Wxiw"):
+        t = copy.deepcopy(pr0)
+        t[key] = list(cases[1][1][key])           # a valid point of another proof
+        cases.append((pub0, t))
+    t = copy.deepcopy(pr0)
+    t["T1"][0] = str((int(t["T1"][0]) + 1) % b.Q)  # off the curve
+    cases.append((pub0, t))
+    t = copy.deepcopy(pr0)
+    t["eval_b"] = str(int(t["eval_b"]) + b.R)      # evaluation given as value + r: reduced, still valid
+    if int(t["eval_b"]) < (1 << 256):
+        cases.append((pub0, t))
+    ver = amd.PlonkVerifier(_vk_json(zk))
+    got = ver.verify_batch(cases)
+
+    def oracle(ps, po):
+        try:
+            return pk.verify(vk, [int(x) % b.R for x in ps], pk.proof_from_obj(po))
+        except Exception:
+            return False
+    exp = [oracle(ps, po) for ps, po in cases]
+    assert got == exp
+    assert got[:3] == [True, True, True] and not any(got[3:13])
+    assert ver.verify(pub0, pr0) is True and ver.verify(pub0[:-1], pr0) is False
+    t = copy.deepcopy(pr0)
+    t["C"][1] = str(int(t["C"][1]) + b.Q)          # non-canonical coordinate: rejected (the oracle would reduce it)
+    assert ver.verify(pub0, t) is False
+    # the device prover's proof through the device verifier
+    prover = amd.PlonkProver(pk.write_zkey(zk))
+    gp, gpub = prover.prove(f.write_wtns(w))
+    prover.close()
+    assert ver.verify(gpub, gp) is True
+    ver.close()

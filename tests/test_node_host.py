@@ -182,6 +182,14 @@ def test_node_plonk_setup_from_ptau_files(addon, tmp_path):
     vk = pk.vkey(zk)
     assert vkj["Qm"] == ([str(vk["Qm"][0]), str(vk["Qm"][1]), "1"] if vk["Qm"] else ["0", "1", "0"])
     assert pk.verify(vk, [int(x) for x in json.loads(puf.read_text())], pk.proof_from_obj(json.loads(prf.read_text())))
+    # ... and `plonk verify` closes the flow on the GPU: OK for the proof, "Invalid proof" for a changed public signal
+    r = subprocess.run(["node", cli, "plonk", "verify", str(vkf), str(puf), str(prf)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "snarkJS: OK!" in r.stdout, r.stderr
+    pubs = json.loads(puf.read_text())
+    pubs[0] = str(int(pubs[0]) + 1)
+    puf.write_text(json.dumps(pubs))
+    r = subprocess.run(["node", cli, "plonk", "verify", str(vkf), str(puf), str(prf)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 1 and "Invalid proof" in r.stderr
     r = subprocess.run(["node", cli, "plonk", "setup", str(rf), str(tmp_path / "missing.ptau"), str(zf)], capture_output=True, text=True, timeout=120)
     assert r.returncode == 1 and "cannot open" in r.stderr
 
