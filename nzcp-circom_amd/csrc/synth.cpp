@@ -15,6 +15,7 @@
 #include <string.h>
 
 #include <atomic>
+#include <new>
 #include <thread>
 
 #include "internal.h"
@@ -1119,7 +1120,24 @@ static int read_r1cs(const uint8_t* buf, size_t len, Circuit& c) {
   memcpy(&nPrvIn, s1 + 48, 4); memcpy(&nCons, s1 + 60, 4);
   (void)nPrvIn;
   c.n = nWires; c.p = nPubOut + nPubIn; c.m = nCons;
-  if (c.n < c.p + 1 || c.m == 0) return bad("inconsistent header");
+  if (c.n < c.p + 1 || c.m == 0 || (uint64_t)nPubOut + nPubIn >= nWires) return bad("inconsistent header");
+  // an untrusted header must not size the allocations: every constraint takes >= 12 bytes of section 2, and a wire
+  // that appears nowhere still has its 8-byte entry in the wire map (section 3) when the file carries one
+  if ((uint64_t)nCons * 12 > l2) return bad("constraint count exceeds the constraint section");
+  if (nWires > (1u << 28)) return bad("too many wires");
+  {
+    const uint8_t* s3 = nullptr;
+    uint64_t l3 = 0;
+    size_t q3 = 12;
+    for (uint32_t i = 0; i < nsec; i++) {
+      uint32_t id; uint64_t sz;
+      memcpy(&id, buf + q3, 4); memcpy(&sz, buf + q3 + 4, 8); q3 += 12;
+      if (id == 3 && !s3) { s3 = buf + q3; l3 = sz; }
+      q3 += sz;
+    }
+    if (s3 && l3 != (uint64_t)nWires * 8) return bad("wire map does not match the wire count");
+    if (!s3 && (uint64_t)nWires > l2) return bad("wire count exceeds the file");
+  }
   c.rowA.assign(1, 0); c.rowB.assign(1, 0); c.rowC.assign(1, 0);
   const uint8_t* q = s2;
   const uint8_t* end = s2 + l2;
@@ -1147,12 +1165,17 @@ static int read_r1cs(const uint8_t* buf, size_t len, Circuit& c) {
 extern "C" int g16_r1cs_setup(const uint8_t* r1cs, size_t r1cs_len, uint64_t seed, int threads, uint8_t** zkey,
                               size_t* zkey_len, uint8_t** vkey, size_t* vkey_len) {
   if (!zkey || !zkey_len) { set_error("NULL argument"); return G16_E_ARG; }
-  Circuit c;
-  int rc = read_r1cs(r1cs, r1cs_len, c);
-  if (rc) return rc;
-  uint64_t need = (uint64_t)c.m + c.p + 1;
-  if (need > ((uint64_t)1 << 27)) { set_error("r1cs: circuit too large"); return G16_E_ARG; }
-  return setup_core(c, seed, threads, zkey, zkey_len, vkey, vkey_len);
+  try {
+    Circuit c;
+    int rc = read_r1cs(r1cs, r1cs_len, c);
+    if (rc) return rc;
+    uint64_t need = (uint64_t)c.m + c.p + 1;
+    if (need > ((uint64_t)1 << 27)) { set_error("r1cs: circuit too large"); return G16_E_ARG; }
+    return setup_core(c, seed, threads, zkey, zkey_len, vkey, vkey_len);
+  } catch (const std::bad_alloc&) {   // no C++ exception crosses the C ABI
+    set_error("setup: out of memory");
+    return G16_E_STATE;
+  }
 }
 
 // ------------------------------------------------------------------ PLONK setup (test-only: tau is known)
@@ -1427,7 +1450,12 @@ extern "C" int g16_plonk_setup(const uint8_t* r1cs, size_t r1cs_len, uint64_t se
   PlonkTauSrc src;
   src.known = true;
   src.seed = seed;
-  return plonk_setup_core(r1cs, r1cs_len, src, device, with_lagrange, zkey, zkey_len);
+  try {
+    return plonk_setup_core(r1cs, r1cs_len, src, device, with_lagrange, zkey, zkey_len);
+  } catch (const std::bad_alloc&) {   // no C++ exception crosses the C ABI
+    set_error("plonk setup: out of memory");
+    return G16_E_STATE;
+  }
 }
 
 // `snarkjs plonk setup c.r1cs pot.ptau c.zkey` (/root/reference/Makefile:31) with a REAL powers-of-tau file: .ptau v1
@@ -1473,7 +1501,12 @@ extern "C" int g16_plonk_setup_ptau(const uint8_t* r1cs, size_t r1cs_len, const 
   src.tau_g1 = sp[2];
   src.n_g1 = sl[2] / 64;
   src.tau_g2_1 = sp[3] + 128;
-  return plonk_setup_core(r1cs, r1cs_len, src, device, with_lagrange, zkey, zkey_len);
+  try {
+    return plonk_setup_core(r1cs, r1cs_len, src, device, with_lagrange, zkey, zkey_len);
+  } catch (const std::bad_alloc&) {
+    set_error("plonk setup: out of memory");
+    return G16_E_STATE;
+  }
 }
 
 // File-path form of g16_plonk_setup_ptau for hosts that cannot hold a ceremony file in one buffer (a Node.js Buffer

@@ -211,3 +211,48 @@ def test_parsers_survive_mutated_keys(amd):
                 ctor(bytes(b))
             codes.add(e.value.code)
         assert codes <= {-2, -4, -1} and -2 in codes
+
+
+def test_r1cs_and_ptau_readers_survive_mutated_files(amd):
+    """Mutated .r1cs / .ptau images: an error (or a valid setup), never a crash or an allocation sized by an untrusted
+    header field (r02: a mutated wire count made the reader allocate 100+ GB)."""
+    import random
+    import struct
+    import torch
+    import plonk as pk
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    _, rows, _ = synth.gen_circuit(60, 5, 40, 3)
+    r = f.write_r1cs(60, 5, 0, rows)
+    pt = pk.write_ptau(6, 777)
+    rng = random.Random(2)
+
+    def mutate(buf, head):
+        b = bytearray(buf)
+        k = rng.randrange(4)
+        if k == 0:
+            for _j in range(rng.randrange(1, 4)):
+                b[rng.randrange(min(len(b), head))] = rng.randrange(256)
+        elif k == 1:
+            b = b[:rng.randrange(len(b))]
+        elif k == 2:
+            i = rng.randrange(min(len(b) - 4, head))
+            b[i:i + 4] = struct.pack("<I", rng.choice([0, 1, 0xffffffff, 0x7fffffff, rng.randrange(1 << 32)]))
+        else:
+            i = 12 + rng.randrange(100)
+            b[i:i + 8] = struct.pack("<Q", rng.choice([0, 1, len(b), 1 << 40, (1 << 64) - 1]))
+        return bytes(b)
+    codes = set()
+    for _ in range(600):
+        m = mutate(r, len(r))
+        for fn in (lambda x: amd.r1cs_setup(x, 1, 2), lambda x: amd.plonk_setup(x, 1, device=0)):
+            try:
+                fn(m)
+            except amd.G16Error as e:
+                codes.add(e.value.code if hasattr(e, "value") else e.code)
+    for _ in range(400):
+        try:
+            amd.plonk_setup_ptau(r, mutate(pt, 400), device=0)
+        except amd.G16Error as e:
+            codes.add(e.code)
+    assert codes <= {-1, -2, -4, -5}
