@@ -147,3 +147,41 @@ def test_two_handles_prove_concurrently_from_two_threads(amd):
     assert got[1] == want1 and got[2] == want2
     p1.close()
     p2.close()
+
+
+def test_mutated_witness_files_are_refused_or_proved(amd):
+    """A .wtns image is untrusted input too: flipped header bytes, truncations and absurd section sizes end in
+    G16_E_FORMAT with snarkjs's texts -- or, when only witness VALUES changed, in a proof (of a false statement: the
+    prover does not judge the witness) -- never in a fault."""
+    import random
+    import struct
+    from conftest import golden_path
+    zk = open(golden_path("small.zkey"), "rb").read()
+    w = open(golden_path("small.wtns"), "rb").read()
+    prover = amd.Prover(zk)
+    rng = random.Random(9)
+    outcomes = {"proved": 0, "refused": 0}
+    for _ in range(300):
+        b = bytearray(w)
+        k = rng.randrange(4)
+        if k == 0:
+            for _j in range(rng.randrange(1, 4)):
+                b[rng.randrange(min(len(b), 90))] = rng.randrange(256)
+        elif k == 1:
+            b = b[:rng.randrange(len(b))]
+        elif k == 2:
+            i = rng.randrange(len(b) - 4)
+            b[i:i + 4] = struct.pack("<I", rng.choice([0, 1, 0xffffffff, 0x7fffffff, rng.randrange(1 << 32)]))
+        else:
+            i = 12 + rng.randrange(60)
+            b[i:i + 8] = struct.pack("<Q", rng.choice([0, 1, len(b), 1 << 40, (1 << 64) - 1]))
+        try:
+            prover.prove(bytes(b))
+            outcomes["proved"] += 1
+        except amd.G16Error as e:
+            assert e.code == -2, (e.code, str(e))
+            outcomes["refused"] += 1
+    assert outcomes["refused"] > 100 and outcomes["proved"] > 0
+    proof, pub = prover.prove(w)      # the handle is still good
+    assert len(pub) == prover.info.n_public
+    prover.close()
