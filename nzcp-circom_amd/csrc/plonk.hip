@@ -423,6 +423,43 @@ __global__ void k_copy1(const FrM* __restrict__ src, FrM* __restrict__ dst) {
   if (threadIdx.x == 0 && blockIdx.x == 0) dst[0] = src[0];
 }
 
+// Several evaluations at once (round 4: a, b, c, s1, s2, t at xi and z at xi w): blockIdx.y = the job
+struct EvalJob { const FrM* pol; uint32_t n; FrM x, xc; };
+struct EvalJobs { EvalJob j[8]; uint32_t stride; };
+__global__ __launch_bounds__(256) void k_horner_multi(EvalJobs jobs, FrM* __restrict__ H) {
+  const EvalJob& jb = jobs.j[blockIdx.y];
+  const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t lo = c * kHorner;
+  if (lo >= jb.n) return;
+  const uint32_t hi = lo + kHorner < jb.n ? lo + kHorner : jb.n;
+  FrM r = fp_zero<FrParams>();
+  for (uint32_t i = hi; i-- > lo;) r = fp_add(fp_mul(r, jb.x), jb.pol[i]);
+  H[(size_t)blockIdx.y * jobs.stride + c] = r;
+}
+// one workgroup per job: the chunk values combined (as k_suffix_horner), only the total kept: out[job] = P_job(x_job)
+__global__ __launch_bounds__(1024) void k_suffix_total_multi(EvalJobs jobs, const FrM* __restrict__ H, FrM* __restrict__ out) {
+  __shared__ FrM sm[1024];
+  const EvalJob& jb = jobs.j[blockIdx.x];
+  const FrM* h = H + (size_t)blockIdx.x * jobs.stride;
+  const uint32_t nc = (jb.n + kHorner - 1) / kHorner;
+  const uint32_t t = threadIdx.x;
+  const uint32_t B = (nc + 1023) / 1024;
+  const uint32_t lo = t * B < nc ? t * B : nc, hi = lo + B < nc ? lo + B : nc;
+  FrM r = fp_zero<FrParams>();
+  for (uint32_t i = hi; i-- > lo;) r = fp_add(h[i], fp_mul(jb.xc, r));
+  sm[t] = r;
+  FrM pw = fp_pow_u64(jb.xc, B);
+  __syncthreads();
+  for (uint32_t d = 1; d < 1024; d <<= 1) {
+    const FrM v = t + d < 1024 ? sm[t + d] : fp_zero<FrParams>();
+    __syncthreads();
+    sm[t] = fp_add(sm[t], fp_mul(pw, v));
+    pw = fp_sqr(pw);
+    __syncthreads();
+  }
+  if (t == 0) out[blockIdx.x] = sm[0];
+}
+
 struct R4Args { FrM coefz, coef_ab, ea, eb, ec, coefs3; };
 // pol_r[i] = coefz z[i] (+ coef_ab qm + ea ql + eb qr + ec qo + qc - coefs3 s3 for i < n), i < n + 3
 __global__ __launch_bounds__(256) void k_pol_r(const FrM* __restrict__ z, const FrM* __restrict__ qm, const FrM* __restrict__ ql,
@@ -735,8 +772,9 @@ int plonk_create_impl(const uint8_t* zkey, size_t len, int device, g16_plonk* P)
   G16_HIP(hipMalloc(&P->d_wraw, (size_t)P->nBase * 32));
   G16_HIP(hipMalloc(&P->d_w, (size_t)P->nVars * 32));
   G16_HIP(hipMalloc(&P->d_scal, ((size_t)N + 8) * 32));
-  G16_HIP(hipMalloc(&P->d_tot, (n4 / kChunk + 8) * 32));
-  G16_HIP(hipMalloc(&P->d_tot2, (n4 / kChunk + 8) * 32));
+  const size_t tot_n = std::max<size_t>(n4 / kChunk + 8, 8 * ((3 * (size_t)N + 8) / kHorner + 2));
+  G16_HIP(hipMalloc(&P->d_tot, tot_n * 32));
+  G16_HIP(hipMalloc(&P->d_tot2, tot_n * 32));
   G16_HIP(hipMalloc(&P->d_evals, 8 * 32));
   G16_HIP(hipMalloc(&P->d_bad, 64));
   // w_4N^i and the 4N evaluations of L1 = NTT(iNTT(e_0))
@@ -1032,13 +1070,20 @@ int plonk_prove_impl(g16_plonk* P, const uint8_t* wtns, size_t wlen, const uint8
   FrM et;
   const FrM xiw = fp_mul(xi, P->w1);
   {
-    if ((rc = eval_pol_async(P, P->d_pa, N + 2, xi, 0))) return rc;
-    if ((rc = eval_pol_async(P, P->d_pb, N + 2, xi, 1))) return rc;
-    if ((rc = eval_pol_async(P, P->d_pc, N + 2, xi, 2))) return rc;
-    if ((rc = eval_pol_async(P, P->d_pol[5], N, xi, 3))) return rc;
-    if ((rc = eval_pol_async(P, P->d_pol[6], N, xi, 4))) return rc;
-    if ((rc = eval_pol_async(P, P->d_T, 3 * N + 6, xi, 5))) return rc;
-    if ((rc = eval_pol_async(P, P->d_pz, N + 3, xiw, 6))) return rc;
+    EvalJobs jobs;
+    const FrM xic = h_pow(xi, kHorner), xiwc = h_pow(xiw, kHorner);
+    jobs.j[0] = EvalJob{P->d_pa, N + 2, xi, xic};
+    jobs.j[1] = EvalJob{P->d_pb, N + 2, xi, xic};
+    jobs.j[2] = EvalJob{P->d_pc, N + 2, xi, xic};
+    jobs.j[3] = EvalJob{P->d_pol[5], N, xi, xic};
+    jobs.j[4] = EvalJob{P->d_pol[6], N, xi, xic};
+    jobs.j[5] = EvalJob{P->d_T, 3 * N + 6, xi, xic};
+    jobs.j[6] = EvalJob{P->d_pz, N + 3, xiw, xiwc};
+    jobs.j[7] = jobs.j[6];
+    jobs.stride = (3 * N + 8) / kHorner + 2;
+    k_horner_multi<<<dim3(nblk(jobs.stride), 7), 256, 0, st>>>(jobs, P->d_tot);
+    k_suffix_total_multi<<<7, 1024, 0, st>>>(jobs, P->d_tot, P->d_evals);
+    G16_HIP(hipGetLastError());
     FrM evs[7];
     if ((rc = read_evals(P, evs, 7))) return rc;
     pr->ea = evs[0]; pr->eb = evs[1]; pr->ec = evs[2]; pr->es1 = evs[3]; pr->es2 = evs[4]; et = evs[5]; pr->ezw = evs[6];
