@@ -66,8 +66,10 @@ traffic = {
     "method": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum in separate passes with "
               "--kernel-trace (MI355X_MICROARCH.md HBM section); counters are KiB -> x1024. FETCH_SIZE is reported RAW: "
               "the guide's x2 correction is calibrated for 16 B/lane coalesced streams only; these are 64-byte random "
-              "gathers (4 x dwordx4 per lane, one aligned 64-byte sector per point), for which TCC_MISS_sum x 64 B gives "
-              "the same figure within ~5 %, so no correction is applied.",
+              "gathers (4 x dwordx4 per lane, one aligned 64-byte sector per point), calibrated on a known byte count in "
+              "this very pattern (tools/fetch_calib.hip, profiles/r02_fetch_size_calibration.txt: reading / true bytes = "
+              "1.000 for random 64-byte gathers, 0.500 for the same loads on consecutive records and for 16 B/lane "
+              "streams); TCC_MISS_sum x 64 B gives the same figure within ~5 %.",
     "source": f"profiles/{tag}_pmc_accumulate.txt (tools/profile_round.sh + tools/pmc_summary.py)",
 }
 json.dump(traffic, open(os.path.join(prof, f"{tag}_pmc_traffic.json"), "w"), indent=1)
