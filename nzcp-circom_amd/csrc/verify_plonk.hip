@@ -24,6 +24,7 @@
 
 #include "internal.h"
 #include "pairing.cuh"
+#include "transcript.h"
 
 namespace g16 {
 namespace {
@@ -89,76 +90,16 @@ __global__ __launch_bounds__(64) void pv_final_kernel(const Fq12* __restrict__ m
   ok[i] = f12_is_one(final_exponentiation(f, pc)) ? 1 : 0;
 }
 
-// ---- host: Keccak transcript + scalar arithmetic (the prover's helpers, restated here to keep the units independent)
-void keccak_f(uint64_t s[25]) {
-  static const uint64_t RC[24] = {
-      0x0000000000000001ull, 0x0000000000008082ull, 0x800000000000808Aull, 0x8000000080008000ull, 0x000000000000808Bull,
-      0x0000000080000001ull, 0x8000000080008081ull, 0x8000000000008009ull, 0x000000000000008Aull, 0x0000000000000088ull,
-      0x0000000080008009ull, 0x000000008000000Aull, 0x000000008000808Bull, 0x800000000000008Bull, 0x8000000000008089ull,
-      0x8000000000008003ull, 0x8000000000008002ull, 0x8000000000000080ull, 0x000000000000800Aull, 0x800000008000000Aull,
-      0x8000000080008081ull, 0x8000000000008080ull, 0x0000000080000001ull, 0x8000000080008008ull};
-  static const int ROT[25] = {0, 1, 62, 28, 27, 36, 44, 6, 55, 20, 3, 10, 43, 25, 39, 41, 45, 15, 21, 8, 18, 2, 61, 56, 14};
-  auto rol = [](uint64_t x, int n) { return n ? (x << n) | (x >> (64 - n)) : x; };
-  for (int r = 0; r < 24; r++) {
-    uint64_t c[5], d[5], b[25];
-    for (int x = 0; x < 5; x++) c[x] = s[x] ^ s[x + 5] ^ s[x + 10] ^ s[x + 15] ^ s[x + 20];
-    for (int x = 0; x < 5; x++) d[x] = c[(x + 4) % 5] ^ rol(c[(x + 1) % 5], 1);
-    for (int i = 0; i < 25; i++) s[i] ^= d[i % 5];
-    for (int x = 0; x < 5; x++)
-      for (int y = 0; y < 5; y++) b[y + 5 * ((2 * x + 3 * y) % 5)] = rol(s[x + 5 * y], ROT[x + 5 * y]);
-    for (int x = 0; x < 5; x++)
-      for (int y = 0; y < 5; y++) s[x + 5 * y] = b[x + 5 * y] ^ ((~b[(x + 1) % 5 + 5 * y]) & b[(x + 2) % 5 + 5 * y]);
-    s[0] ^= RC[r];
-  }
-}
+// ---- host: scalar helpers (the Keccak transcript lives in transcript.h, shared with the prover)
+using transcript::hash_to_fr;
+using transcript::put_fr_be;
 bool lt_words(const uint32_t v[8], const uint32_t m[8]) {
   for (int l = 7; l >= 0; l--)
     if (v[l] != m[l]) return v[l] < m[l];
   return false;
 }
-Fr hash_to_fr(const std::vector<uint8_t>& t) {   // Keccak-256 digest as a big-endian integer mod r, Montgomery form
-  const size_t rate = 136;
-  std::vector<uint8_t> m(t);
-  m.push_back(0x01);
-  while (m.size() % rate) m.push_back(0);
-  m.back() |= 0x80;
-  uint64_t s[25] = {0};
-  for (size_t off = 0; off < m.size(); off += rate) {
-    for (size_t i = 0; i < rate / 8; i++) {
-      uint64_t v = 0;
-      for (int k = 7; k >= 0; k--) v = (v << 8) | m[off + 8 * i + k];
-      s[i] ^= v;
-    }
-    keccak_f(s);
-  }
-  uint8_t h[32];
-  for (int i = 0; i < 4; i++)
-    for (int k = 0; k < 8; k++) h[8 * i + k] = (uint8_t)(s[i] >> (8 * k));
-  Fr x;
-  for (int l = 0; l < 8; l++) {
-    uint32_t w = 0;
-    for (int k = 0; k < 4; k++) w = (w << 8) | h[32 - 4 * (l + 1) + k];
-    x.v[l] = w;
-  }
-  static const uint32_t kR[8] = G16_FR_P;
-  while (!lt_words(x.v, kR)) {
-    int64_t br = 0;
-    for (int i = 0; i < 8; i++) {
-      br += (int64_t)x.v[i] - (int64_t)kR[i];
-      x.v[i] = (uint32_t)br;
-      br >>= 32;
-    }
-  }
-  return fp_to_mont(x);
-}
 void put_be(std::vector<uint8_t>& t, const uint8_t le[32]) {   // a 32-byte LE standard-form word, big-endian
   for (int k = 31; k >= 0; k--) t.push_back(le[k]);
-}
-void put_fr_be(std::vector<uint8_t>& t, const Fr& mont) {
-  const Fr s = fp_from_mont(mont);
-  uint8_t b[32];
-  memcpy(b, s.v, 32);
-  put_be(t, b);
 }
 Fr root_of_unity(uint32_t power) {
   Fr w = {G16_FR_W28};
