@@ -50,3 +50,20 @@ def test_gates_hold_and_proof_verifies(n, p, m, seed):
     assert pk.proof_from_obj(pk.proof_obj(proof)) == proof
     z = pk.write_zkey(zk)
     assert z[:4] == b"zkey" and len(pk.write_zkey(zk, with_lagrange=False)) < len(z)
+
+
+def test_oracle_reproduces_the_plonk_golden_fixture():
+    """tests/golden/plonk_small.* (make_golden_plonk.py): the oracle still produces the committed key, proof and
+    verification key -- a change of the restatement shows up here, not only in the GPU parity tests."""
+    import json
+    import formats as f
+    from conftest import golden_path
+    meta = json.load(open(golden_path("plonk_small.json")))
+    rows, w = synth.make(meta["n"], meta["p"], meta["m"], meta["seed"])
+    zk = pk.setup(meta["n"], meta["p"], rows, int(meta["tau"]))
+    assert pk.write_zkey(zk) == open(golden_path("plonk_small.zkey"), "rb").read()
+    assert f.write_wtns(w) == open(golden_path("plonk_small.wtns"), "rb").read()
+    bl = {i + 1: int(x) for i, x in enumerate(meta["blinding"])}
+    proof, pub = pk.prove(zk, w, bl)
+    assert pk.proof_obj(proof) == meta["proof"] and [str(x) for x in pub] == meta["public"]
+    assert pk.verify(pk.vkey(zk), pub, pk.proof_from_obj(meta["proof"]))

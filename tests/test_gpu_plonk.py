@@ -228,3 +228,19 @@ def test_plonk_verifier_verdicts_equal_oracle(amd, n, p, m, seed):
     prover.close()
     assert ver.verify(gpub, gp) is True
     ver.close()
+
+
+def test_device_prover_and_verifier_on_the_golden_fixture(amd):
+    """tests/golden/plonk_small.*: the committed key and witness, proved on the device with the committed blinding, give
+    the committed proof.json / public.json; the device verifier accepts it against the committed verification key."""
+    import json
+    from conftest import golden_path
+    meta = json.load(open(golden_path("plonk_small.json")))
+    prover = amd.PlonkProver(open(golden_path("plonk_small.zkey"), "rb").read())
+    proof, pub = prover.prove(open(golden_path("plonk_small.wtns"), "rb").read(), [int(x) for x in meta["blinding"]])
+    prover.close()
+    assert proof == meta["proof"] and pub == meta["public"]
+    ver = amd.PlonkVerifier(meta["vkey"])
+    assert ver.verify(pub, proof) is True
+    assert ver.verify([str(int(pub[0]) + 1)] + pub[1:], proof) is False
+    ver.close()
