@@ -151,6 +151,10 @@ size_t msm_point_bytes(int curve);   // canonical XYZZ bytes: 128 (G1) / 256 (G2
 int msm_group_create(MsmGroup& g, const MsmSectionIn* secs, int nsec, const MsmConfig& cfg);
 void msm_group_destroy(MsmGroup& g);
 int msm_workspace_create(MsmWorkspace** ws, const MsmGroup& g);
+// priority of the streams the NEXT workspaces created on this thread make for themselves (the G2 lane's dup-row
+// stream); kMsmPrioHighest = the device's highest (default).  See prover.cpp create_impl: hardware-queue pools.
+static constexpr int kMsmPrioHighest = -1000;
+void msm_set_aux_stream_priority(int prio);
 void msm_workspace_destroy(MsmWorkspace* ws);
 // Per-section results of one launch: XYZZ sums in the canonical Montgomery(2^256) image.
 struct MsmResult {

@@ -725,6 +725,9 @@ void msm_group_destroy(MsmGroup& g) {
   g.n = 0;
 }
 
+static thread_local int t_aux_prio = kMsmPrioHighest;
+void msm_set_aux_stream_priority(int prio) { t_aux_prio = prio; }
+
 static int lane_create(MsmLaneWs& ln, const MsmGroup& g, int curve, uint32_t key_lo, uint32_t key_hi, uint32_t point_base,
                        uint64_t entries, uint64_t entries_eff) {
   ln.active = true;
@@ -789,6 +792,7 @@ static int lane_create(MsmLaneWs& ln, const MsmGroup& g, int curve, uint32_t key
     if (curve == 2) {   // G2: its own stream beside the bucket reduce (G1's dup stage is short: it stays on the lane's
       int plo = 0, phi = 0;   // stream -- hardware queues are scarce, see prover.cpp create_impl)
       G16_HIP(hipDeviceGetStreamPriorityRange(&plo, &phi));
+      if (t_aux_prio != kMsmPrioHighest) phi = t_aux_prio;
       G16_HIP(hipStreamCreateWithPriority(&ln.st_dup, hipStreamNonBlocking, phi));
     }
     G16_HIP(hipEventCreateWithFlags(&ln.ev_dup_fork, hipEventDisableTiming));

@@ -99,6 +99,33 @@ __global__ __launch_bounds__(256) void k_pad4(const FrM* __restrict__ coefs, uin
   if (i >= 4 * n) return;
   out[i] = i < n ? coefs[i] : fp_zero<FrParams>();
 }
+// g^j for j < 2^24 from two 4096-entry tables: hi[j >> 12] * lo[j & 4095] (Montgomery words)
+struct PowTab { const FrM* lo; const FrM* hi; };
+__device__ __forceinline__ FrM pow_tab(const PowTab& t, uint32_t j) { return fp_mul(t.hi[j >> 12], t.lo[j & 4095u]); }
+// the coefficients of p(g X), zero padded to n4: the 4N-point transform of these is p on the coset g <w_4N>
+__global__ __launch_bounds__(256) void k_pad4_coset(const FrM* __restrict__ coefs, uint32_t len, uint32_t n4, PowTab g,
+                                                    FrM* __restrict__ out) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n4) return;
+  out[i] = i < len ? fp_mul(coefs[i], pow_tab(g, i)) : fp_zero<FrParams>();
+}
+// back from the coefficients of t(g X) to those of t; bad[0] is set when a coefficient at or above `keep` is not zero
+// (the numerator was not a multiple of X^n - 1: snarkjs' "T Polynomial is not divisible")
+__global__ __launch_bounds__(256) void k_uncoset_check(FrM* __restrict__ t, uint32_t n4, uint32_t keep, PowTab ginv,
+                                                       uint32_t* __restrict__ bad) {
+  const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= n4) return;
+  const FrM v = t[j];
+  if (j >= keep) {
+    if (!fp_is_zero(v)) atomicOr(&bad[0], 1u);
+    return;
+  }
+  t[j] = fp_mul(v, pow_tab(ginv, j));
+}
+__global__ __launch_bounds__(256) void k_mul_const(FrM* __restrict__ x, size_t n, FrM c) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) x[i] = fp_mul(x[i], c);
+}
 // out[i] = w^i, i < n (each lane: one power by square-and-multiply, then kChunk successive products)
 __global__ __launch_bounds__(256) void k_powers(FrM w, uint32_t n, FrM* __restrict__ out) {
   const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
@@ -161,10 +188,17 @@ __global__ __launch_bounds__(256) void k_z_apply(const FrM* __restrict__ lp, con
   if (i + 1 < n) Z[i + 1] = fp_mul(carry[i / kChunk], lp[i]);
 }
 
-// Round 3 runs on the 9 x 29-bit lazy Montgomery field of the NTT kernels (fr29.cuh: 241 instructions per product
-// against ~530 of the canonical 8x32 product): its inputs are the 4N-point transforms left in the lazy format (no
-// export), its outputs go straight into the inverse transforms' working vectors (no import).  Discipline: every sum and
-// difference is weak-reduced (< 1.0001 r), so every product input is < 2.5 r and every subtrahend < 3 r.
+// Round 3.  snarkjs evaluates the UNBLINDED polynomials on the 4N subgroup and carries the blinding factors along as
+// a second polynomial (T and Tz, `mul4` with its Z1/Z2/Z3 tables), because X^n - 1 vanishes on a quarter of that
+// domain and the quotient has to be taken coefficient-wise.  The quotient polynomial t itself does not depend on how
+// it is computed, so this prover evaluates the BLINDED polynomials on the coset g <w_4N> (g = w_8N: X^n - 1 takes four
+// non-zero values there), forms numerator / (X^n - 1) point by point and transforms back: 21 products per point instead
+// of 77, one inverse transform instead of two, and the same coefficients bit for bit.
+//
+// It runs on the 9 x 29-bit lazy Montgomery field of the NTT kernels (fr29.cuh: 241 instructions per product against
+// ~530 of the canonical 8x32 product): its inputs are the 4N-point transforms left in the lazy format (no export), its
+// output goes straight into the inverse transform's working vector (no import).  Discipline: every sum and difference
+// is weak-reduced (< 1.0001 r), so every product input is < 2.5 r and every subtrahend < 3 r.
 using L9 = F29;
 __device__ __forceinline__ L9 lmul(const L9& a, const L9& b) { return fr29_mul(a, b); }
 __device__ __forceinline__ L9 ladd(const L9& a, const L9& b) { return fr29_weak_reduce(fr29_add(a, b)); }
@@ -175,91 +209,33 @@ __global__ __launch_bounds__(256) void k_to_lazy(const FrM* __restrict__ in, L9*
   out[i] = fr29_from_fr(in[i]);
 }
 struct R3Args {
-  L9 beta, gamma, alpha, alpha2, k1, k2, w1, one;
-  L9 b[10];
-  L9 Z1[4], Z2[4], Z3[4];
+  L9 beta, gamma, alpha, alpha2, k1, k2, one;
+  L9 zhinv[4];   // 1 / (x^n - 1) at x = g w_4N^i: depends on i mod 4 only
 };
 struct R3Ptrs {
-  const L9 *A4, *B4, *C4, *Z4, *qm, *ql, *qr, *qo, *qc, *s1, *s2, *s3, *pi4, *l1, *om4;
+  const L9 *A4, *B4, *C4, *Z4, *qm, *ql, *qr, *qo, *qc, *s1, *s2, *s3, *pi4, *l1, *x4;
 };
-// the coefficients of t^k of prod (x_k + xp_k t), one linear factor at a time
-__device__ __forceinline__ void poly_mul_lin(L9* c, int deg, const L9& x, const L9& xp) {
-  L9 carry = f29_zero();
-  for (int k = 0; k <= deg; k++) {
-    const L9 lo = lmul(c[k], x);
-    const L9 hi = lmul(c[k], xp);
-    c[k] = k ? ladd(lo, carry) : lo;
-    carry = hi;
-  }
-  c[deg + 1] = carry;
-}
-__device__ __forceinline__ void mul4z(const L9& x, const L9& y, const L9& u, const L9& v, const L9& xp, const L9& yp,
-                                      const L9& up, const L9& vp, uint32_t p, const R3Args& a, L9& r, L9& rz) {
-  L9 c[5];
-  c[0] = x;
-  c[1] = xp;
-  poly_mul_lin(c, 1, y, yp);
-  poly_mul_lin(c, 2, u, up);
-  poly_mul_lin(c, 3, v, vp);
-  r = c[0];
-  rz = c[1];
-  if (p) rz = ladd(rz, ladd(lmul(a.Z1[p], c[2]), ladd(lmul(a.Z2[p], c[3]), lmul(a.Z3[p], c[4]))));
-}
-__global__ __launch_bounds__(256) void k_round3(R3Ptrs q, R3Args a, uint32_t n4, L9* __restrict__ T, L9* __restrict__ Tz) {
+__global__ __launch_bounds__(256) void k_round3(R3Ptrs q, R3Args a, uint32_t n4, L9* __restrict__ T) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n4) return;
-  const uint32_t p = i & 3u;
-  const L9 w = q.om4[i];
-  // (transform outputs may sit anywhere below 16 r: reduce on load)
-  const L9 A = fr29_weak_reduce(q.A4[i]), B = fr29_weak_reduce(q.B4[i]), C = fr29_weak_reduce(q.C4[i]);
-  const L9 Z = fr29_weak_reduce(q.Z4[i]), ZW = fr29_weak_reduce(q.Z4[(i + 4) % n4]);
-  const L9 ap = ladd(a.b[2], lmul(a.b[1], w));
-  const L9 bp = ladd(a.b[4], lmul(a.b[3], w));
-  const L9 cp = ladd(a.b[6], lmul(a.b[5], w));
-  const L9 w2 = lmul(w, w);
-  const L9 zp = ladd(ladd(lmul(a.b[7], w2), lmul(a.b[8], w)), a.b[9]);
-  const L9 ww = lmul(w, a.w1);
-  const L9 zwp = ladd(ladd(lmul(a.b[7], lmul(ww, ww)), lmul(a.b[8], ww)), a.b[9]);
+  auto ld = [&](const L9* v, uint32_t k) { return fr29_weak_reduce(v[k]); };   // (transform outputs may sit anywhere below 16 r)
+  const L9 A = ld(q.A4, i), B = ld(q.B4, i), C = ld(q.C4, i);
   // gate
-  const L9 qm = q.qm[i], ql = q.ql[i], qr = q.qr[i], qo = q.qo[i];
-  L9 e1 = lmul(lmul(A, B), qm);
-  L9 e1z = ladd(lmul(A, bp), lmul(ap, B));
-  if (p) e1z = ladd(e1z, lmul(a.Z1[p], lmul(ap, bp)));
-  e1z = lmul(e1z, qm);
-  const L9 pi = fr29_weak_reduce(q.pi4[i]);
-  e1 = ladd(e1, ladd(ladd(lmul(A, ql), lmul(B, qr)), ladd(lmul(C, qo), ladd(pi, q.qc[i]))));
-  e1z = ladd(e1z, ladd(ladd(lmul(ap, ql), lmul(bp, qr)), lmul(cp, qo)));
+  L9 e = lmul(lmul(A, B), ld(q.qm, i));
+  e = ladd(e, ladd(lmul(A, ld(q.ql, i)), lmul(B, ld(q.qr, i))));
+  e = ladd(e, ladd(lmul(C, ld(q.qo, i)), ladd(ld(q.pi4, i), ld(q.qc, i))));
   // permutation
-  const L9 bw = lmul(a.beta, w);
-  L9 e2, e2z, e3, e3z;
-  mul4z(ladd(ladd(A, bw), a.gamma), ladd(ladd(B, lmul(bw, a.k1)), a.gamma), ladd(ladd(C, lmul(bw, a.k2)), a.gamma), Z, ap, bp, cp,
-        zp, p, a, e2, e2z);
-  mul4z(ladd(ladd(A, lmul(a.beta, q.s1[i])), a.gamma), ladd(ladd(B, lmul(a.beta, q.s2[i])), a.gamma),
-        ladd(ladd(C, lmul(a.beta, q.s3[i])), a.gamma), ZW, ap, bp, cp, zwp, p, a, e3, e3z);
-  const L9 l1 = fr29_weak_reduce(q.l1[i]);
-  const L9 e4 = lmul(lmul(lsub(Z, a.one), l1), a.alpha2);
-  const L9 e4z = lmul(lmul(zp, l1), a.alpha2);
-  T[i] = ladd(ladd(e1, lmul(a.alpha, lsub(e2, e3))), e4);
-  Tz[i] = ladd(ladd(e1z, lmul(a.alpha, lsub(e2z, e3z))), e4z);
-}
-// t = numerator / (X^n - 1) on 4n coefficients, in place: q_j = -p_j, q_{j+kn} = q_{j+(k-1)n} - p_{j+kn}; bad[0] is set
-// when a coefficient above 3n - 4 of the quotient is not zero.  Then t += tz below 3n + 6 (bad[1]: tz not zero above).
-__global__ __launch_bounds__(256) void k_div_zh(FrM* __restrict__ t, const FrM* __restrict__ tz, uint32_t n, uint32_t* __restrict__ bad) {
-  const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
-  if (j >= n) return;
-  FrM qv = fp_neg(t[j]);
-  t[j] = fp_add(qv, tz[j]);
-  for (uint32_t k = 1; k < 4; k++) {
-    const uint32_t i = j + k * n;
-    qv = fp_sub(qv, t[i]);
-    if (i > 3 * n - 4 && !fp_is_zero(qv)) atomicOr(&bad[0], 1u);
-    if (i > 3 * n + 5) {
-      if (!fp_is_zero(tz[i])) atomicOr(&bad[1], 1u);
-      t[i] = qv;
-    } else {
-      t[i] = fp_add(qv, tz[i]);
-    }
-  }
+  const L9 bx = lmul(a.beta, q.x4[i]);
+  L9 e2 = lmul(ladd(ladd(A, bx), a.gamma), ladd(ladd(B, lmul(bx, a.k1)), a.gamma));
+  e2 = lmul(e2, ladd(ladd(C, lmul(bx, a.k2)), a.gamma));
+  const L9 Z = ld(q.Z4, i);
+  e2 = lmul(e2, Z);
+  L9 e3 = lmul(ladd(ladd(A, lmul(a.beta, ld(q.s1, i))), a.gamma), ladd(ladd(B, lmul(a.beta, ld(q.s2, i))), a.gamma));
+  e3 = lmul(e3, ladd(ladd(C, lmul(a.beta, ld(q.s3, i))), a.gamma));
+  e3 = lmul(e3, ld(q.Z4, (i + 4) % n4));   // z(w X)
+  e = ladd(e, lmul(a.alpha, lsub(e2, e3)));
+  e = ladd(e, lmul(lmul(lsub(Z, a.one), ld(q.l1, i)), a.alpha2));
+  T[i] = lmul(e, a.zhinv[i & 3u]);
 }
 // H[c] = sum_{j < len_c} P[c kHorner + j] x^j
 __global__ __launch_bounds__(256) void k_horner(const FrM* __restrict__ P, uint32_t n, FrM x, FrM* __restrict__ H) {
@@ -453,7 +429,11 @@ struct g16_plonk {
   uint32_t *d_add_s1 = nullptr, *d_add_s2 = nullptr, *d_add_order = nullptr;
   FrM *d_add_f1 = nullptr, *d_add_f2 = nullptr;
   std::vector<uint32_t> level_start;
-  F29 *d_om4 = nullptr, *d_l1 = nullptr;   // w_4N^i and L1 on the 4N domain, lazy format
+  F29 *d_om4 = nullptr, *d_l1 = nullptr;   // the points g w_4N^i of the round-3 coset and L1 on it, lazy format
+  FrM* d_gtab = nullptr;                   // 4 x 4096 words: g^j (lo, hi) and g^-j (lo, hi), see PowTab
+  FrM gN;                                  // g^N
+  PowTab tab_g() const { return PowTab{d_gtab, d_gtab + 4096}; }
+  PowTab tab_ginv() const { return PowTab{d_gtab + 8192, d_gtab + 12288}; }
   MsmGroup srs;
   MsmWorkspace* ws = nullptr;             // slot 0 of the commitment lanes (on the main stream)
   MsmWorkspace* wsx[2] = {nullptr, nullptr};   // slots 1, 2: independent commitments of a round run side by side
@@ -466,14 +446,14 @@ struct g16_plonk {
   FrM *d_A = nullptr, *d_B = nullptr, *d_C = nullptr, *d_Z = nullptr;   // N evaluations
   FrM *d_pa = nullptr, *d_pb = nullptr, *d_pc = nullptr, *d_pz = nullptr;   // blinded coefficient forms (N + 3)
   F29 *d_A4 = nullptr, *d_B4 = nullptr, *d_C4 = nullptr, *d_Z4 = nullptr, *d_pi4 = nullptr;   // 4N evaluations, lazy format
-  FrM *d_T = nullptr, *d_Tz = nullptr;  // 4N canonical words: padding scratch, then the quotient's coefficients
+  FrM* d_T = nullptr;                   // 4N canonical words: padding scratch, then the quotient's coefficients
   FrM *d_tmpN = nullptr, *d_tmpN2 = nullptr, *d_tmpN3 = nullptr, *d_tmpN4 = nullptr;   // N-sized scratch
   FrM *d_cA = nullptr, *d_cB = nullptr, *d_cC = nullptr, *d_cZ = nullptr;   // unblinded coefficients (the side stream pads them)
   FrM *d_pi_ev = nullptr, *d_pi_co = nullptr;
   FrM *d_r = nullptr, *d_wxi = nullptr, *d_q = nullptr;
   FrM *d_tot = nullptr, *d_tot2 = nullptr;   // chunk totals / Horner partials, and their combined carries
   FrM* d_evals = nullptr;               // 8 evaluation results, read back once per round
-  F29 *d_lazy = nullptr, *d_lazy2 = nullptr;   // 4N lazy elements each: the transforms' working vectors (T and Tz in round 3)
+  F29 *d_lazy = nullptr, *d_lazy2 = nullptr;   // 4N lazy elements each: the transforms' working vectors (d_lazy: t in round 3)
   Fr* d_scal = nullptr;                 // N + 6 standard-form MSM scalars
   uint32_t* d_bad = nullptr;
   float last_ms[6] = {};
@@ -485,7 +465,7 @@ struct g16_plonk {
     for (auto p : d_pol) if (p) (void)hipFree(p);
     for (auto p : d_map) if (p) (void)hipFree(p);
     void* v[] = {d_add_s1, d_add_s2, d_add_order, d_add_f1, d_add_f2, d_om4, d_l1, d_wraw, d_w, d_A, d_B, d_C, d_Z, d_pa, d_pb, d_pc,
-                 d_pz, d_A4, d_B4, d_C4, d_Z4, d_T, d_Tz, d_pi4, d_tmpN, d_tmpN2, d_tmpN3, d_tmpN4, d_r, d_wxi, d_q, d_tot, d_lazy, d_lazy2, d_cA, d_cB, d_cC, d_cZ, d_pi_ev, d_pi_co, d_tot2, d_evals,
+                 d_pz, d_A4, d_B4, d_C4, d_Z4, d_T, d_gtab, d_pi4, d_tmpN, d_tmpN2, d_tmpN3, d_tmpN4, d_r, d_wxi, d_q, d_tot, d_lazy, d_lazy2, d_cA, d_cB, d_cC, d_cZ, d_pi_ev, d_pi_co, d_tot2, d_evals,
                  d_scal, d_bad};
     for (void* p : v) if (p) (void)hipFree(p);
     if (ws) msm_workspace_destroy(ws);
@@ -614,6 +594,23 @@ int plonk_create_impl(const uint8_t* zkey, size_t len, int device, g16_plonk* P)
   hipStream_t st = P->st;
   if ((rc = ntt_tables_create(P->ntt_n, (int)P->L, st))) return rc;
   if ((rc = ntt_tables_create(P->ntt_4n, (int)P->L + 2, st))) return rc;
+  {   // the round-3 coset: g = w_8N (g^4N = -1, so X^N - 1 has no zero on g <w_4N>), powers of g and 1/g by two-level tables
+    if (P->L + 2 > 24) { set_error("zkey: domain too large for the round-3 tables"); return G16_E_FORMAT; }
+    const FrM g = h_root((int)P->L + 3), gi = fp_inv(g);
+    P->gN = h_pow(g, N);
+    std::vector<FrM> tab(4 * 4096);
+    const FrM base[2] = {g, gi};
+    for (int t = 0; t < 2; t++) {
+      FrM* lo = tab.data() + t * 8192;
+      FrM* hi = lo + 4096;
+      lo[0] = hi[0] = fp_one<FrParams>();
+      for (int k = 1; k < 4096; k++) lo[k] = fp_mul(lo[k - 1], base[t]);
+      const FrM step = fp_mul(lo[4095], base[t]);
+      for (int k = 1; k < 4096; k++) hi[k] = fp_mul(hi[k - 1], step);
+    }
+    G16_HIP(hipMalloc(&P->d_gtab, tab.size() * 32));
+    G16_HIP(hipMemcpy(P->d_gtab, tab.data(), tab.size() * 32, hipMemcpyHostToDevice));
+  }
   // polynomials: coefficients (N) then evaluations (4N)
   // the selectors' 4N evaluations pass through d_T (allocated here, scratch of the proofs later) on their way to the
   // lazy format
@@ -629,9 +626,11 @@ int plonk_create_impl(const uint8_t* zkey, size_t len, int device, g16_plonk* P)
       dst = P->d_ext[k];
     }
     G16_HIP(hipMemcpyAsync(P->d_pol[k], src, (size_t)N * 32, hipMemcpyHostToDevice, st));
-    G16_HIP(hipMemcpyAsync(dst, src + (size_t)N * 32, (size_t)N * 128, hipMemcpyHostToDevice, st));
-    k_to_lazy<<<nblk((size_t)N * 4), 256, 0, st>>>(dst, P->d_ext_l[k], (size_t)N * 4);
+    if (k >= 5) G16_HIP(hipMemcpyAsync(dst, src + (size_t)N * 32, (size_t)N * 128, hipMemcpyHostToDevice, st));
+    // round 3 wants the polynomial on the coset g <w_4N>, not the zkey's subgroup evaluations: transformed here
+    k_pad4_coset<<<nblk((size_t)N * 4), 256, 0, st>>>(P->d_pol[k], N, (uint32_t)(N * 4), P->tab_g(), d_stage);
     G16_HIP(hipGetLastError());
+    if ((rc = fft_to_lazy(P->ntt_4n, d_stage, P->d_ext_l[k], st))) return rc;
   }
   G16_HIP(hipStreamSynchronize(st));
   // maps, zero padded to N
@@ -683,7 +682,6 @@ int plonk_create_impl(const uint8_t* zkey, size_t len, int device, g16_plonk* P)
   }
   // scratch
   const size_t n4 = (size_t)N * 4;
-  G16_HIP(hipMalloc(&P->d_Tz, n4 * 32));   // (d_T: above)
   F29** four_l[] = {&P->d_A4, &P->d_B4, &P->d_C4, &P->d_Z4, &P->d_pi4, &P->d_om4, &P->d_l1, &P->d_lazy, &P->d_lazy2};
   for (F29** p : four_l) G16_HIP(hipMalloc(p, n4 * sizeof(F29)));
   FrM** one[] = {&P->d_A, &P->d_B, &P->d_C, &P->d_Z, &P->d_tmpN, &P->d_tmpN2, &P->d_tmpN3, &P->d_tmpN4,
@@ -699,15 +697,16 @@ int plonk_create_impl(const uint8_t* zkey, size_t len, int device, g16_plonk* P)
   G16_HIP(hipMalloc(&P->d_tot2, tot_n * 32));
   G16_HIP(hipMalloc(&P->d_evals, 8 * 32));
   G16_HIP(hipMalloc(&P->d_bad, 64));
-  // w_4N^i and the 4N evaluations of L1 = NTT(iNTT(e_0))
+  // the coset points g w_4N^i and L1 = iNTT(e_0) on them
   k_powers<<<nblk(nblk(n4, kChunk)), 256, 0, st>>>(h_root((int)P->L + 2), (uint32_t)n4, P->d_T);
+  k_mul_const<<<nblk(n4), 256, 0, st>>>(P->d_T, n4, h_root((int)P->L + 3));
   k_to_lazy<<<nblk(n4), 256, 0, st>>>(P->d_T, P->d_om4, n4);
   {
     G16_HIP(hipMemsetAsync(P->d_tmpN, 0, (size_t)N * 32, st));
     const FrM one_m = fp_one<FrParams>();
     G16_HIP(hipMemcpyAsync(P->d_tmpN, &one_m, 32, hipMemcpyHostToDevice, st));
     if ((rc = do_ifft(P->ntt_n, P->d_tmpN, P->d_tmpN2, P->d_lazy, st))) return rc;
-    k_pad4<<<nblk(n4), 256, 0, st>>>(P->d_tmpN2, N, P->d_T);
+    k_pad4_coset<<<nblk(n4), 256, 0, st>>>(P->d_tmpN2, N, (uint32_t)n4, P->tab_g(), P->d_T);
     if ((rc = fft_to_lazy(P->ntt_4n, P->d_T, P->d_l1, st))) return rc;
   }
   G16_HIP(hipGetLastError());
@@ -891,8 +890,8 @@ int plonk_prove_impl(g16_plonk* P, const uint8_t* wtns, size_t wlen, const uint8
     G16_HIP(hipGetLastError());
     return G16_OK;
   };
-  auto ext_of = [&](const FrM* coefs, F29* ext) -> int {
-    k_pad4<<<nblk(n4), 256, 0, st2>>>(coefs, N, P->d_T);
+  auto ext_of = [&](const FrM* coefs, uint32_t len, F29* ext) -> int {   // `len` coefficients -> the round-3 coset
+    k_pad4_coset<<<nblk(n4), 256, 0, st2>>>(coefs, len, (uint32_t)n4, P->tab_g(), P->d_T);
     G16_HIP(hipGetLastError());
     return fft_to_lazy(P->ntt_4n, P->d_T, ext, st2);   // the evaluations stay in the lazy format for round 3
   };
@@ -902,13 +901,13 @@ int plonk_prove_impl(g16_plonk* P, const uint8_t* wtns, size_t wlen, const uint8
   if ((rc = to_pol(P->d_C, pzc, P->d_pc, P->d_cC))) return rc;
   G16_HIP(hipEventRecord(P->ev_fork, st));
   G16_HIP(hipStreamWaitEvent(st2, P->ev_fork, 0));
-  if ((rc = ext_of(P->d_cA, P->d_A4))) return rc;
-  if ((rc = ext_of(P->d_cB, P->d_B4))) return rc;
-  if ((rc = ext_of(P->d_cC, P->d_C4))) return rc;
+  if ((rc = ext_of(P->d_pa, N + 2, P->d_A4))) return rc;   // the BLINDED polynomials (see k_round3)
+  if ((rc = ext_of(P->d_pb, N + 2, P->d_B4))) return rc;
+  if ((rc = ext_of(P->d_pc, N + 2, P->d_C4))) return rc;
   {   // the public-input polynomial on the 4N domain
     k_pi_evals<<<nblk(N), 256, 0, st2>>>(P->d_A, P->nPublic, N, P->d_pi_ev);
     if ((rc = do_ifft(P->ntt_n, P->d_pi_ev, P->d_pi_co, P->d_lazy2, st2))) return rc;
-    if ((rc = ext_of(P->d_pi_co, P->d_pi4))) return rc;
+    if ((rc = ext_of(P->d_pi_co, N, P->d_pi4))) return rc;
   }
   {
     const FrM* cf[3] = {P->d_pa, P->d_pb, P->d_pc};
@@ -940,7 +939,7 @@ int plonk_prove_impl(g16_plonk* P, const uint8_t* wtns, size_t wlen, const uint8
   if ((rc = to_pol(P->d_Z, pzz, P->d_pz, P->d_cZ))) return rc;
   G16_HIP(hipEventRecord(P->ev_fork, st));
   G16_HIP(hipStreamWaitEvent(st2, P->ev_fork, 0));
-  if ((rc = ext_of(P->d_cZ, P->d_Z4))) return rc;
+  if ((rc = ext_of(P->d_pz, N + 3, P->d_Z4))) return rc;
   G16_HIP(hipEventRecord(P->ev_join, st2));
   if ((rc = commit(P, P->d_pz, N + 3, &pr->Z))) return rc;
   lap(1);
@@ -953,28 +952,27 @@ int plonk_prove_impl(g16_plonk* P, const uint8_t* wtns, size_t wlen, const uint8
     R3Args a;
     auto lz = [](const FrM& x) { return fr29_from_fr(x); };
     a.beta = lz(beta); a.gamma = lz(gamma); a.alpha = lz(alpha); a.alpha2 = lz(fp_sqr(alpha)); a.k1 = lz(P->k1); a.k2 = lz(P->k2);
-    a.w1 = lz(P->w1);
-    for (int i = 0; i < 10; i++) a.b[i] = lz(b[i]);
-    const FrM i4 = h_root(2), one = fp_one<FrParams>(), two = fp_add(one, one), zero = fp_zero<FrParams>();
-    const FrM m1 = fp_neg(one), m2 = fp_neg(two), four = fp_add(two, two), m8 = fp_neg(fp_add(four, four));
-    a.one = lz(one);
-    a.Z1[0] = lz(zero); a.Z1[1] = lz(fp_add(m1, i4)); a.Z1[2] = lz(m2); a.Z1[3] = lz(fp_sub(m1, i4));
-    a.Z2[0] = lz(zero); a.Z2[1] = lz(fp_mul(m2, i4)); a.Z2[2] = lz(four); a.Z2[3] = lz(fp_neg(fp_mul(m2, i4)));
-    a.Z3[0] = lz(zero); a.Z3[1] = lz(fp_add(two, fp_mul(two, i4))); a.Z3[2] = lz(m8); a.Z3[3] = lz(fp_sub(two, fp_mul(two, i4)));
+    a.one = lz(fp_one<FrParams>());
+    {   // x^N - 1 at x = g w_4N^i is g^N i4^(i mod 4) - 1
+      const FrM i4 = h_root(2);
+      FrM v = P->gN;
+      for (int k = 0; k < 4; k++) {
+        a.zhinv[k] = lz(fp_inv(fp_sub(v, fp_one<FrParams>())));
+        v = fp_mul(v, i4);
+      }
+    }
     R3Ptrs q{P->d_A4, P->d_B4, P->d_C4, P->d_Z4, P->d_ext_l[0], P->d_ext_l[1], P->d_ext_l[2], P->d_ext_l[3], P->d_ext_l[4],
              P->d_ext_l[5], P->d_ext_l[6], P->d_ext_l[7], P->d_pi4, P->d_l1, P->d_om4};
-    k_round3<<<nblk(n4), 256, 0, st>>>(q, a, (uint32_t)n4, P->d_lazy, P->d_lazy2);   // T and Tz, natural order, lazy
+    k_round3<<<nblk(n4), 256, 0, st>>>(q, a, (uint32_t)n4, P->d_lazy);   // t on the coset, natural order, lazy
     G16_HIP(hipGetLastError());
     if ((rc = ifft_from_lazy(P->ntt_4n, P->d_lazy, P->d_T, st))) return rc;
-    if ((rc = ifft_from_lazy(P->ntt_4n, P->d_lazy2, P->d_Tz, st))) return rc;
-    k_div_zh<<<nblk(N), 256, 0, st>>>(P->d_T, P->d_Tz, N, P->d_bad);
+    k_uncoset_check<<<nblk(n4), 256, 0, st>>>(P->d_T, (uint32_t)n4, 3 * N + 6, P->tab_ginv(), P->d_bad);
     G16_HIP(hipGetLastError());
     uint32_t bad[3] = {0, 0, 0};
     G16_HIP(hipMemcpyAsync(bad, P->d_bad, 12, hipMemcpyDeviceToHost, st));
     G16_HIP(hipStreamSynchronize(st));
     if (bad[2]) { set_error("Copy constraints does not match"); return G16_E_STATE; }
     if (bad[0]) { set_error("T Polynomial is not divisible"); return G16_E_STATE; }
-    if (bad[1]) { set_error("Tz Polynomial is not well calculated"); return G16_E_STATE; }
   }
   {
     const FrM* cf[3] = {P->d_T, P->d_T + N, P->d_T + 2 * (size_t)N};

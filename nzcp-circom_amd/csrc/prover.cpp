@@ -381,15 +381,21 @@ static int create_impl(const uint8_t* zkey, size_t len, const g16_opts* opts, g1
   const bool serial = getenv("G16_SERIAL_MSM") && atoi(getenv("G16_SERIAL_MSM"));
   for (int ci = 0; ci < g16_prover::kCtx; ci++) {
     auto& c = P->ctx[ci];
-    if (ci > 0) {   // later contexts: same streams, created after context 0 has its queues
-      G16_HIP(hipStreamCreateWithPriority(&c.st, hipStreamNonBlocking, prio_hi));
+    if (ci > 0) {
+      // later contexts (batch pipelining): their three busy streams come from the NORMAL-priority pool.  HIP has 4
+      // hardware queues per priority level; context 0 holds three of the high ones, so a second high-priority trio
+      // shares queues with it -- and with itself: r02 kernel trace of g16_prove_batch, context 1's G2 lane sat on its
+      // own main stream's queue, FIFO in front of the H-MSM (two proofs in flight took 2 x the time of one).
+      const int prio_ctx = (prio_lo > prio_hi + 1 && !getenv("G16_CTX_SAME_PRIO")) ? prio_hi + 1 : prio_hi;
+      G16_HIP(hipStreamCreateWithPriority(&c.st, hipStreamNonBlocking, prio_ctx));
       if (serial) {
         c.wst = c.wst2 = c.st;
       } else {
-        G16_HIP(hipStreamCreateWithPriority(&c.wst2, hipStreamNonBlocking, prio_hi));
+        G16_HIP(hipStreamCreateWithPriority(&c.wst2, hipStreamNonBlocking, prio_ctx));
         G16_HIP(hipStreamCreateWithPriority(&c.wst, hipStreamNonBlocking, prio_lo));
       }
       for (auto& e : c.ev) G16_HIP(hipEventCreate(&e));
+      msm_set_aux_stream_priority(prio_ctx);
     }
     for (int i = 0; i < 3; i++) {
       if ((rc = msm_workspace_create(&c.ws[i], P->grp[i]))) return rc;   // (creates the G2 lane's dup-row stream)
@@ -405,6 +411,7 @@ static int create_impl(const uint8_t* zkey, size_t len, const g16_opts* opts, g1
     G16_HIP(hipHostMalloc((void**)&c.h_flag, 64));
     *c.h_flag = 0xffffffffu;
   }
+  msm_set_aux_stream_priority(kMsmPrioHighest);
   G16_HIP(hipStreamSynchronize(P->st));
   return G16_OK;
 }
@@ -941,23 +948,33 @@ int g16_prove_batch(g16_prover* p, const uint8_t* const* wtns, const size_t* wtn
     const int wrc = witness_ok(c);
     return wrc ? wrc : frc;
   };
+  static const bool trace = getenv("G16_TRACE_HOST") != nullptr;
+  const auto tb0 = std::chrono::steady_clock::now();
+  auto now_ms = [&]() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tb0).count(); };
   for (size_t i = 0; i < count; i++) {
     ProofCtx& c = p->ctx[i % g16_prover::kCtx];
+    const double t_a = now_ms();
     if (i >= (size_t)g16_prover::kCtx) {   // the context is still busy with proof i - kCtx
       int rc = finish_one(i - g16_prover::kCtx);
       if (rc) return rc;
     }
+    const double t_b = now_ms();
     const uint8_t* body = nullptr;
     int rc = parse_wtns(p, wtns[i], wtns_lens[i], &body);
     if (rc) return rc;
     G16_HIP(hipSetDevice(p->device));
     if (!c.d_w) G16_HIP(hipMalloc(&c.d_w, wbytes));
     G16_HIP(hipMemcpyAsync(c.d_w, body, wbytes, hipMemcpyHostToDevice, c.st));
+    const double t_c = now_ms();
     if ((rc = qap_check_witness(c.d_w, p->nVars, c.d_flag, c.h_flag, c.st))) return rc;
     if (pub && p->nPublic) memcpy(pub + i * (size_t)p->nPublic * 32, body + 32, (size_t)p->nPublic * 32);
     if ((rc = launch_ctx(p, c, c.d_w))) return rc;
+    const double t_d = now_ms();
     bl_rc[i % g16_prover::kCtx] = prepare_blinding(&p->kp, rs ? rs + i * 64 : nullptr, rs ? rs + i * 64 + 32 : nullptr,
                                                     bl[i % g16_prover::kCtx]);
+    if (trace)
+      fprintf(stderr, "[g16 batch] proof %zu: at %.3f ms  finish(i-%d) %.3f  upload call %.3f  launch %.3f  blinding %.3f\n", i,
+              t_a, g16_prover::kCtx, t_b - t_a, t_c - t_b, t_d - t_c, now_ms() - t_d);
   }
   for (size_t i = count > (size_t)g16_prover::kCtx ? count - g16_prover::kCtx : 0; i < count; i++) {
     int rc = finish_one(i);
