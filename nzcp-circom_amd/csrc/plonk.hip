@@ -99,25 +99,31 @@ __global__ __launch_bounds__(256) void k_pad4(const FrM* __restrict__ coefs, uin
   if (i >= 4 * n) return;
   out[i] = i < n ? coefs[i] : fp_zero<FrParams>();
 }
-// g^j for j < 2^24 from two 4096-entry tables: hi[j >> 12] * lo[j & 4095] (Montgomery words)
+// g^j from two tables: hi[j >> 12] * lo[j & 4095] (Montgomery words)
 struct PowTab { const FrM* lo; const FrM* hi; };
 __device__ __forceinline__ FrM pow_tab(const PowTab& t, uint32_t j) { return fp_mul(t.hi[j >> 12], t.lo[j & 4095u]); }
-// the coefficients of p(g X), zero padded to n4: the 4N-point transform of these is p on the coset g <w_4N>
-__global__ __launch_bounds__(256) void k_pad4_coset(const FrM* __restrict__ coefs, uint32_t len, uint32_t n4, PowTab g,
-                                                    FrM* __restrict__ out) {
-  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n4) return;
-  out[i] = i < len ? fp_mul(coefs[i], pow_tab(g, i)) : fp_zero<FrParams>();
+// The coefficients of p(g X), zero padded to 4N -- the 4N-point transform of these is p on the coset g <w_4N> -- written
+// straight into the forward transform's working vector: lazy format, bit-reversed order (what ntt_dit_forward
+// reads).  A GATHER: output p takes coefficient bitrev(p), and only a quarter of the outputs have one
+// (ntt_import scatters 40-byte elements: 1.3-2.1 ms per 2^24 vector against 0.3 here).
+__global__ __launch_bounds__(256) void k_coset_import(const FrM* __restrict__ coefs, uint32_t len, int L4, PowTab g,
+                                                      F29* __restrict__ out) {
+  const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= (1u << L4)) return;
+  const uint32_t src = __brev(p) >> (32 - L4);
+  out[p] = src < len ? fr29_from_fr(fp_mul(coefs[src], pow_tab(g, src))) : f29_zero();
 }
-// back from the coefficients of t(g X) to those of t; bad[0] is set when a coefficient at or above `keep` is not zero
-// (the numerator was not a multiple of X^n - 1: snarkjs' "T Polynomial is not divisible")
-__global__ __launch_bounds__(256) void k_uncoset_check(FrM* __restrict__ t, uint32_t n4, uint32_t keep, PowTab ginv,
-                                                       uint32_t* __restrict__ bad) {
+// Back from t(g X) to t: coefficient j of the inverse transform (its working vector is lazy, bit-reversed, unscaled: a
+// gather again) times g^-j / 4N; bad[0] is set when a coefficient at or above `keep` is not zero (the numerator was not
+// a multiple of X^n - 1: snarkjs' "T Polynomial is not divisible")
+__global__ __launch_bounds__(256) void k_coset_export_check(const F29* __restrict__ in, F29 ninv, int L4, uint32_t keep,
+                                                            PowTab ginv, FrM* __restrict__ t, uint32_t* __restrict__ bad) {
   const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
-  if (j >= n4) return;
-  const FrM v = t[j];
+  if (j >= (1u << L4)) return;
+  const FrM v = fr29_to_fr(fr29_mul(in[__brev(j) >> (32 - L4)], ninv));
   if (j >= keep) {
     if (!fp_is_zero(v)) atomicOr(&bad[0], 1u);
+    t[j] = v;
     return;
   }
   t[j] = fp_mul(v, pow_tab(ginv, j));
@@ -430,10 +436,11 @@ struct g16_plonk {
   FrM *d_add_f1 = nullptr, *d_add_f2 = nullptr;
   std::vector<uint32_t> level_start;
   F29 *d_om4 = nullptr, *d_l1 = nullptr;   // the points g w_4N^i of the round-3 coset and L1 on it, lazy format
-  FrM* d_gtab = nullptr;                   // 4 x 4096 words: g^j (lo, hi) and g^-j (lo, hi), see PowTab
+  FrM* d_gtab = nullptr;                   // g^j as (lo: 4096 words, hi: gtab_hi words), then g^-j likewise: see PowTab
+  size_t gtab_hi = 1;
   FrM gN;                                  // g^N
   PowTab tab_g() const { return PowTab{d_gtab, d_gtab + 4096}; }
-  PowTab tab_ginv() const { return PowTab{d_gtab + 8192, d_gtab + 12288}; }
+  PowTab tab_ginv() const { return PowTab{d_gtab + 4096 + gtab_hi, d_gtab + 8192 + gtab_hi}; }
   MsmGroup srs;
   MsmWorkspace* ws = nullptr;             // slot 0 of the commitment lanes (on the main stream)
   MsmWorkspace* wsx[2] = {nullptr, nullptr};   // slots 1, 2: independent commitments of a round run side by side
@@ -523,19 +530,13 @@ int do_fft(const NttTables& t, const FrM* in, FrM* out, F29* lazy, hipStream_t s
   return rc;
 }
 
-// 4N-point forward transform of canonical coefficients, the evaluations LEFT in the lazy format (natural order)
-int fft_to_lazy(const NttTables& t, const FrM* in, F29* out, hipStream_t st) {
-  int rc = ntt_import(t, in, out, true, st);
+// `len` Montgomery coefficients of p -> p on the round-3 coset g <w_4N>, 4N evaluations in the lazy format (natural order)
+int coset_fft(g16_plonk* P, const FrM* d_coefs, uint32_t len, F29* out, hipStream_t st) {
+  const size_t n4 = (size_t)P->N * 4;
+  k_coset_import<<<nblk(n4), 256, 0, st>>>(d_coefs, len, (int)P->L + 2, P->tab_g(), out);
+  G16_HIP(hipGetLastError());
   F29* v[1] = {out};
-  if (!rc) rc = ntt_dit_forward(t, v, 1, st);
-  return rc;
-}
-// inverse transform of a lazy vector in place, result exported as canonical coefficients
-int ifft_from_lazy(const NttTables& t, F29* inout, FrM* out, hipStream_t st) {
-  F29* v[1] = {inout};
-  int rc = ntt_dif_inverse(t, v, 1, st);
-  if (!rc) rc = ntt_export(t, inout, out, true, true, st);
-  return rc;
+  return ntt_dit_forward(P->ntt_4n, v, 1, st);
 }
 
 int plonk_create_impl(const uint8_t* zkey, size_t len, int device, g16_plonk* P) {
@@ -567,7 +568,7 @@ int plonk_create_impl(const uint8_t* zkey, size_t len, int device, g16_plonk* P)
   memcpy(P->k1.v, h + 20, 32);
   memcpy(P->k2.v, h + 52, 32);
   const uint32_t N = P->N;
-  if (N < 4 || (N & (N - 1)) || N > (1u << 24) || P->nCons > N || P->nAdd > P->nVars || P->nPublic >= P->nVars - P->nAdd) {
+  if (N < 8 || (N & (N - 1)) || N > (1u << 24) || P->nCons > N || P->nAdd > P->nVars || P->nPublic >= P->nVars - P->nAdd) {
     set_error("zkey: Invalid File format");
     return G16_E_FORMAT;
   }
@@ -595,18 +596,18 @@ int plonk_create_impl(const uint8_t* zkey, size_t len, int device, g16_plonk* P)
   if ((rc = ntt_tables_create(P->ntt_n, (int)P->L, st))) return rc;
   if ((rc = ntt_tables_create(P->ntt_4n, (int)P->L + 2, st))) return rc;
   {   // the round-3 coset: g = w_8N (g^4N = -1, so X^N - 1 has no zero on g <w_4N>), powers of g and 1/g by two-level tables
-    if (P->L + 2 > 24) { set_error("zkey: domain too large for the round-3 tables"); return G16_E_FORMAT; }
     const FrM g = h_root((int)P->L + 3), gi = fp_inv(g);
     P->gN = h_pow(g, N);
-    std::vector<FrM> tab(4 * 4096);
+    P->gtab_hi = std::max<size_t>(1, ((size_t)N * 4) >> 12);
+    std::vector<FrM> tab(2 * (4096 + P->gtab_hi));
     const FrM base[2] = {g, gi};
     for (int t = 0; t < 2; t++) {
-      FrM* lo = tab.data() + t * 8192;
+      FrM* lo = tab.data() + t * (4096 + P->gtab_hi);
       FrM* hi = lo + 4096;
       lo[0] = hi[0] = fp_one<FrParams>();
       for (int k = 1; k < 4096; k++) lo[k] = fp_mul(lo[k - 1], base[t]);
       const FrM step = fp_mul(lo[4095], base[t]);
-      for (int k = 1; k < 4096; k++) hi[k] = fp_mul(hi[k - 1], step);
+      for (size_t k = 1; k < P->gtab_hi; k++) hi[k] = fp_mul(hi[k - 1], step);
     }
     G16_HIP(hipMalloc(&P->d_gtab, tab.size() * 32));
     G16_HIP(hipMemcpy(P->d_gtab, tab.data(), tab.size() * 32, hipMemcpyHostToDevice));
@@ -628,9 +629,7 @@ int plonk_create_impl(const uint8_t* zkey, size_t len, int device, g16_plonk* P)
     G16_HIP(hipMemcpyAsync(P->d_pol[k], src, (size_t)N * 32, hipMemcpyHostToDevice, st));
     if (k >= 5) G16_HIP(hipMemcpyAsync(dst, src + (size_t)N * 32, (size_t)N * 128, hipMemcpyHostToDevice, st));
     // round 3 wants the polynomial on the coset g <w_4N>, not the zkey's subgroup evaluations: transformed here
-    k_pad4_coset<<<nblk((size_t)N * 4), 256, 0, st>>>(P->d_pol[k], N, (uint32_t)(N * 4), P->tab_g(), d_stage);
-    G16_HIP(hipGetLastError());
-    if ((rc = fft_to_lazy(P->ntt_4n, d_stage, P->d_ext_l[k], st))) return rc;
+    if ((rc = coset_fft(P, P->d_pol[k], N, P->d_ext_l[k], st))) return rc;
   }
   G16_HIP(hipStreamSynchronize(st));
   // maps, zero padded to N
@@ -706,8 +705,7 @@ int plonk_create_impl(const uint8_t* zkey, size_t len, int device, g16_plonk* P)
     const FrM one_m = fp_one<FrParams>();
     G16_HIP(hipMemcpyAsync(P->d_tmpN, &one_m, 32, hipMemcpyHostToDevice, st));
     if ((rc = do_ifft(P->ntt_n, P->d_tmpN, P->d_tmpN2, P->d_lazy, st))) return rc;
-    k_pad4_coset<<<nblk(n4), 256, 0, st>>>(P->d_tmpN2, N, (uint32_t)n4, P->tab_g(), P->d_T);
-    if ((rc = fft_to_lazy(P->ntt_4n, P->d_T, P->d_l1, st))) return rc;
+    if ((rc = coset_fft(P, P->d_tmpN2, N, P->d_l1, st))) return rc;
   }
   G16_HIP(hipGetLastError());
   G16_HIP(hipStreamSynchronize(st));
@@ -891,9 +889,7 @@ int plonk_prove_impl(g16_plonk* P, const uint8_t* wtns, size_t wlen, const uint8
     return G16_OK;
   };
   auto ext_of = [&](const FrM* coefs, uint32_t len, F29* ext) -> int {   // `len` coefficients -> the round-3 coset
-    k_pad4_coset<<<nblk(n4), 256, 0, st2>>>(coefs, len, (uint32_t)n4, P->tab_g(), P->d_T);
-    G16_HIP(hipGetLastError());
-    return fft_to_lazy(P->ntt_4n, P->d_T, ext, st2);   // the evaluations stay in the lazy format for round 3
+    return coset_fft(P, coefs, len, ext, st2);   // the evaluations stay in the lazy format for round 3
   };
   Pz pza{{b[2], b[1], fp_zero<FrParams>()}, 2}, pzb{{b[4], b[3], fp_zero<FrParams>()}, 2}, pzc{{b[6], b[5], fp_zero<FrParams>()}, 2};
   if ((rc = to_pol(P->d_A, pza, P->d_pa, P->d_cA))) return rc;
@@ -965,9 +961,15 @@ int plonk_prove_impl(g16_plonk* P, const uint8_t* wtns, size_t wlen, const uint8
              P->d_ext_l[5], P->d_ext_l[6], P->d_ext_l[7], P->d_pi4, P->d_l1, P->d_om4};
     k_round3<<<nblk(n4), 256, 0, st>>>(q, a, (uint32_t)n4, P->d_lazy);   // t on the coset, natural order, lazy
     G16_HIP(hipGetLastError());
-    if ((rc = ifft_from_lazy(P->ntt_4n, P->d_lazy, P->d_T, st))) return rc;
-    k_uncoset_check<<<nblk(n4), 256, 0, st>>>(P->d_T, (uint32_t)n4, 3 * N + 6, P->tab_ginv(), P->d_bad);
-    G16_HIP(hipGetLastError());
+    {
+      F29* v[1] = {P->d_lazy};
+      if ((rc = ntt_dif_inverse(P->ntt_4n, v, 1, st))) return rc;
+      Fr n4s = fp_zero<FrParams>();
+      n4s.v[0] = (uint32_t)n4;
+      const F29 ninv = fr29_from_fr(fp_inv(fp_to_mont(n4s)));
+      k_coset_export_check<<<nblk(n4), 256, 0, st>>>(P->d_lazy, ninv, (int)P->L + 2, 3 * N + 6, P->tab_ginv(), P->d_T, P->d_bad);
+      G16_HIP(hipGetLastError());
+    }
     uint32_t bad[3] = {0, 0, 0};
     G16_HIP(hipMemcpyAsync(bad, P->d_bad, 12, hipMemcpyDeviceToHost, st));
     G16_HIP(hipStreamSynchronize(st));

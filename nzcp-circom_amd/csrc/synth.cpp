@@ -1286,7 +1286,7 @@ static int plonk_setup_core(const uint8_t* r1cs, size_t r1cs_len, const PlonkTau
     }
   }
   const size_t ng = pb.gates.size();
-  int L = 2;
+  int L = 3;   // (the quotient polynomial has 3N + 6 coefficients and must fit 4N: snarkjs, too, starts at 2^3)
   while (((size_t)1 << L) < ng) L++;
   if (L > 24) { set_error("plonk setup: circuit too large (more than 2^24 gates)"); return G16_E_ARG; }
   const size_t N = (size_t)1 << L;

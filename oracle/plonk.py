@@ -162,7 +162,7 @@ def _pad4(coefs, n):
 
 def setup(n_vars, n_public, rows, tau):
     gates, adds, pnv = r1cs_to_plonk(n_vars, n_public, rows)
-    power = max(2, (len(gates) - 1).bit_length()) if len(gates) > 1 else 2
+    power = max(3, (len(gates) - 1).bit_length()) if len(gates) > 1 else 3   # t has 3n + 6 coefficients: they must fit 4n
     while (1 << power) < len(gates):
         power += 1
     n = 1 << power
