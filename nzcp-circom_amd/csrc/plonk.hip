@@ -588,8 +588,10 @@ int plonk_create_impl(const uint8_t* zkey, size_t len, int device, g16_plonk* P)
   if (device < 0 || device >= ndev) { set_error("bad device ordinal"); return G16_E_ARG; }
   P->device = device;
   G16_HIP(hipSetDevice(device));
-  G16_HIP(hipStreamCreate(&P->st));
-  G16_HIP(hipStreamCreate(&P->st2));
+  int prio_lo = 0, prio_hi = 0;
+  G16_HIP(hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
+  G16_HIP(hipStreamCreateWithPriority(&P->st, hipStreamNonBlocking, prio_hi));
+  G16_HIP(hipStreamCreateWithPriority(&P->st2, hipStreamNonBlocking, 0));
   G16_HIP(hipEventCreateWithFlags(&P->ev_fork, hipEventDisableTiming));
   G16_HIP(hipEventCreateWithFlags(&P->ev_join, hipEventDisableTiming));
   hipStream_t st = P->st;
@@ -718,9 +720,16 @@ int plonk_create_impl(const uint8_t* zkey, size_t len, int device, g16_plonk* P)
   if ((rc = msm_group_create(P->srs, &sec, 1, cfg))) return rc;
   if (P->srs.n != N + 6) { set_error("zkey: a power of tau is the point at infinity"); return G16_E_FORMAT; }
   if ((rc = msm_workspace_create(&P->ws, P->srs))) return rc;
+  // three of the accumulate kernel's four wavefronts per SIMD (as fast: it is issue-bound), so that the short kernels
+  // of the other commitments -- task queues, reduce tails -- find a slot while it runs
+  const uint32_t acc_waves = getenv("G16_PLONK_ACC_WAVES") ? (uint32_t)atoi(getenv("G16_PLONK_ACC_WAVES")) : 3u;
+  msm_set_waves(P->ws, acc_waves, 0);
   for (int k = 0; k < 2; k++) {
     if ((rc = msm_workspace_create(&P->wsx[k], P->srs))) return rc;
-    G16_HIP(hipStreamCreate(&P->mst[k]));
+    msm_set_waves(P->wsx[k], acc_waves, 0);
+    // (HIP maps streams onto 4 hardware queues per priority level, FIFO within a queue: the main stream and the first
+    // side stream take the high-priority pool, the others the normal one -- r02 trace: slot 0 and slot 2 shared a queue)
+    G16_HIP(hipStreamCreateWithPriority(&P->mst[k], hipStreamNonBlocking, k == 0 ? prio_hi : 0));
     G16_HIP(hipMalloc(&P->d_scalx[k], ((size_t)N + 8) * 32));
   }
   G16_HIP(hipEventCreateWithFlags(&P->ev_pol, hipEventDisableTiming));
@@ -746,7 +755,11 @@ int commit_launch(g16_plonk* P, int slot, const FrM* d_coefs, uint32_t len) {
   }
   k_from_mont_pad<<<nblk(np), 256, 0, s>>>(d_coefs, len, scal, np);
   G16_HIP(hipGetLastError());
-  return msm_launch(P->srs, slot ? P->wsx[slot - 1] : P->ws, scal, s, s);
+  return msm_launch_front(P->srs, slot ? P->wsx[slot - 1] : P->ws, scal, s);   // digits -> sort; commit_lanes: the rest
+}
+int commit_lanes(g16_plonk* P, int slot) {
+  hipStream_t s = slot ? P->mst[slot - 1] : P->st;
+  return msm_launch_lanes(P->srs, slot ? P->wsx[slot - 1] : P->ws, s, s, nullptr, nullptr);
 }
 int commit_collect(g16_plonk* P, int slot, G1Affine* out) {
   MsmResult res;
@@ -757,12 +770,16 @@ int commit_collect(g16_plonk* P, int slot, G1Affine* out) {
 }
 int commit(g16_plonk* P, const FrM* d_coefs, uint32_t len, G1Affine* out) {
   int rc = commit_launch(P, 0, d_coefs, len);
+  if (!rc) rc = commit_lanes(P, 0);
   return rc ? rc : commit_collect(P, 0, out);
 }
 // three (or two) independent commitments at once
 int commit3(g16_plonk* P, const FrM* const coefs[3], const uint32_t lens[3], G1Affine* const outs[3], int count) {
   int rc = G16_OK;
+  // every front end (digits, sorts: memory- and latency-bound, they overlap each other) before any bucket accumulation
+  // (it fills the chip for ~4 ms at 2^22 points and would hold the next commitment's front end back until it is done)
   for (int k = count - 1; k >= 0 && !rc; k--) rc = commit_launch(P, k, coefs[k], lens[k]);   // side slots first: their event precedes slot 0's kernels
+  for (int k = count - 1; k >= 0 && !rc; k--) rc = commit_lanes(P, k);
   for (int k = 0; k < count; k++) {
     const int r = commit_collect(P, k, outs[k]);
     if (r && !rc) rc = r;
