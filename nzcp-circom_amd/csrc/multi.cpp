@@ -135,6 +135,7 @@ int g16_multi_prove(g16_multi* m, const uint8_t* wtns, size_t wtns_len, const ui
     uint32_t lo, hi;
     g16_shard_range(m->N, (int32_t)k, (int32_t)G, &lo, &hi);
     const size_t bytes = (size_t)(hi - lo) * G16_LAZY_FR_BYTES;
+    if (bytes && hipSetDevice(m->dev[k]) != hipSuccess) { set_error("hipSetDevice failed"); rc = G16_E_HIP; break; }
     for (uint32_t v = 0; v < 3 && bytes; v++) {
       const int owner = m->dev[v % G];
       const uint8_t* src = (const uint8_t*)m->vec[v] + (size_t)lo * G16_LAZY_FR_BYTES;
@@ -142,6 +143,10 @@ int g16_multi_prove(g16_multi* m, const uint8_t* wtns, size_t wtns_len, const ui
                                         : hipMemcpyPeer(m->slice[k][v], m->dev[k], src, owner, bytes);
       if (e != hipSuccess) { set_error(std::string("slice copy failed: ") + hipGetErrorString(e)); rc = G16_E_HIP; break; }
     }
+    // A device-to-device hipMemcpy does not wait on the host, and the shards' streams are non-blocking: without this
+    // the slice could still be in flight on the null stream when g16_shard_end reads it (r02: seen once the streams'
+    // hardware queues were reassigned).  Only the null stream is drained: the witness MSMs keep running.
+    if (bytes && !rc && hipStreamSynchronize(nullptr) != hipSuccess) { set_error("slice copy failed"); rc = G16_E_HIP; }
   }
   // 3. join + H-MSM + collect (also run after a failure above, so that every begun shard is drained)
   std::vector<uint8_t> parts(G * G16_PARTIAL_BYTES);
