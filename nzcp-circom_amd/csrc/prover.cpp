@@ -127,7 +127,7 @@ struct g16_prover {
   MsmGroup grp[3];
   bool b2_solo = false;
   bool shard_begun = false;   // between g16_shard_begin and g16_shard_end
-  // Per-proof scratch.  Two contexts so that g16_prove_batch can have proof i+1 on the GPU while the
+  // Per-proof scratch.  Several contexts so that g16_prove_batch can have proof i+1 on the GPU while the
   // host collects and finishes proof i (BASELINE config 3); single proofs use ctx[0].
   struct ProofCtx {
     hipStream_t st = nullptr;                        // QAP -> NTT -> H-MSM (critical chain)
@@ -142,8 +142,9 @@ struct g16_prover {
     uint32_t* h_flag = nullptr;                           // ... its pinned host copy
     g16_timings tm{};
   };
-  static constexpr int kCtx = 2;
+  static constexpr int kCtx = 3;   // at most; `nctx` are created
   ProofCtx ctx[kCtx];
+  int nctx = 3;   // r02 sweep, 512-proof batches: 205 / 257 / 267 proofs/s with 1 / 2 / 3 contexts (each on its own hardware queues)
   std::vector<Fr*> slot_dev;
   std::vector<std::vector<uint8_t>> slot_pub;
   g16_timings tm{};    // of the last completed proof
@@ -379,23 +380,27 @@ static int create_impl(const uint8_t* zkey, size_t len, const g16_opts* opts, g1
   }
   // G16_SERIAL_MSM=1 (profiling aid): every MSM on the main stream, so kernel times are standalone
   const bool serial = getenv("G16_SERIAL_MSM") && atoi(getenv("G16_SERIAL_MSM"));
-  for (int ci = 0; ci < g16_prover::kCtx; ci++) {
+  if (const char* e = getenv("G16_BATCH_CTX")) P->nctx = atoi(e) < 1 ? 1 : (atoi(e) > g16_prover::kCtx ? g16_prover::kCtx : atoi(e));
+  for (int ci = 0; ci < P->nctx; ci++) {
     auto& c = P->ctx[ci];
     if (ci > 0) {
       // later contexts (batch pipelining): their three busy streams come from the NORMAL-priority pool.  HIP has 4
       // hardware queues per priority level; context 0 holds three of the high ones, so a second high-priority trio
       // shares queues with it -- and with itself: r02 kernel trace of g16_prove_batch, context 1's G2 lane sat on its
       // own main stream's queue, FIFO in front of the H-MSM (two proofs in flight took 2 x the time of one).
-      const int prio_ctx = (prio_lo > prio_hi + 1 && !getenv("G16_CTX_SAME_PRIO")) ? prio_hi + 1 : prio_hi;
-      G16_HIP(hipStreamCreateWithPriority(&c.st, hipStreamNonBlocking, prio_ctx));
+      const bool pools = prio_lo > prio_hi + 1 && !getenv("G16_CTX_SAME_PRIO");
+      const int prio_ctx = pools ? prio_hi + 1 : prio_hi;
+      // (a third context -- G16_BATCH_CTX=3, sweeps -- takes what is left: the 4th high queue, the 4th normal one, two low ones)
+      const int p_main = ci == 1 ? prio_ctx : prio_hi, p_g2 = prio_ctx, p_dup = (ci == 1 || !pools) ? prio_ctx : prio_lo;
+      G16_HIP(hipStreamCreateWithPriority(&c.st, hipStreamNonBlocking, p_main));
       if (serial) {
         c.wst = c.wst2 = c.st;
       } else {
-        G16_HIP(hipStreamCreateWithPriority(&c.wst2, hipStreamNonBlocking, prio_ctx));
+        G16_HIP(hipStreamCreateWithPriority(&c.wst2, hipStreamNonBlocking, p_g2));
         G16_HIP(hipStreamCreateWithPriority(&c.wst, hipStreamNonBlocking, prio_lo));
       }
       for (auto& e : c.ev) G16_HIP(hipEventCreate(&e));
-      msm_set_aux_stream_priority(prio_ctx);
+      msm_set_aux_stream_priority(p_dup);
     }
     for (int i = 0; i < 3; i++) {
       if ((rc = msm_workspace_create(&c.ws[i], P->grp[i]))) return rc;   // (creates the G2 lane's dup-row stream)
@@ -932,19 +937,20 @@ int g16_prove_batch(g16_prover* p, const uint8_t* const* wtns, const size_t* wtn
   if (!p || !wtns || !wtns_lens || !out) { set_error("NULL argument"); return G16_E_ARG; }
   std::lock_guard<std::mutex> lk(p->mu);
   if (p->shard_count != 1) { set_error("sharded handle: use g16_prove_partial/g16_prove_finish"); return G16_E_STATE; }
-  // Software pipeline over the two contexts: while the host waits for, folds and finishes proof i-1,
+  // Software pipeline over the contexts: while the host waits for, folds and finishes proof i-1,
   // proof i is already running on the GPU.
   const size_t wbytes = (size_t)p->nVars * sizeof(Fr);
+  const size_t nctx = (size_t)p->nctx;
   Blinding bl[g16_prover::kCtx];
   int bl_rc[g16_prover::kCtx] = {};
   auto finish_one = [&](size_t i) -> int {
-    ProofCtx& c = p->ctx[i % g16_prover::kCtx];
-    if (bl_rc[i % g16_prover::kCtx]) {
+    ProofCtx& c = p->ctx[i % nctx];
+    if (bl_rc[i % nctx]) {
       Partial part;
       (void)collect_ctx(p, c, part);
-      return bl_rc[i % g16_prover::kCtx];
+      return bl_rc[i % nctx];
     }
-    const int frc = collect_and_assemble(p, c, bl[i % g16_prover::kCtx], &out[i]);
+    const int frc = collect_and_assemble(p, c, bl[i % nctx], &out[i]);
     const int wrc = witness_ok(c);
     return wrc ? wrc : frc;
   };
@@ -952,10 +958,10 @@ int g16_prove_batch(g16_prover* p, const uint8_t* const* wtns, const size_t* wtn
   const auto tb0 = std::chrono::steady_clock::now();
   auto now_ms = [&]() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tb0).count(); };
   for (size_t i = 0; i < count; i++) {
-    ProofCtx& c = p->ctx[i % g16_prover::kCtx];
+    ProofCtx& c = p->ctx[i % nctx];
     const double t_a = now_ms();
-    if (i >= (size_t)g16_prover::kCtx) {   // the context is still busy with proof i - kCtx
-      int rc = finish_one(i - g16_prover::kCtx);
+    if (i >= nctx) {   // the context is still busy with proof i - kCtx
+      int rc = finish_one(i - nctx);
       if (rc) return rc;
     }
     const double t_b = now_ms();
@@ -970,13 +976,13 @@ int g16_prove_batch(g16_prover* p, const uint8_t* const* wtns, const size_t* wtn
     if (pub && p->nPublic) memcpy(pub + i * (size_t)p->nPublic * 32, body + 32, (size_t)p->nPublic * 32);
     if ((rc = launch_ctx(p, c, c.d_w))) return rc;
     const double t_d = now_ms();
-    bl_rc[i % g16_prover::kCtx] = prepare_blinding(&p->kp, rs ? rs + i * 64 : nullptr, rs ? rs + i * 64 + 32 : nullptr,
-                                                    bl[i % g16_prover::kCtx]);
+    bl_rc[i % nctx] = prepare_blinding(&p->kp, rs ? rs + i * 64 : nullptr, rs ? rs + i * 64 + 32 : nullptr,
+                                                    bl[i % nctx]);
     if (trace)
       fprintf(stderr, "[g16 batch] proof %zu: at %.3f ms  finish(i-%d) %.3f  upload call %.3f  launch %.3f  blinding %.3f\n", i,
-              t_a, g16_prover::kCtx, t_b - t_a, t_c - t_b, t_d - t_c, now_ms() - t_d);
+              t_a, (int)nctx, t_b - t_a, t_c - t_b, t_d - t_c, now_ms() - t_d);
   }
-  for (size_t i = count > (size_t)g16_prover::kCtx ? count - g16_prover::kCtx : 0; i < count; i++) {
+  for (size_t i = count > nctx ? count - nctx : 0; i < count; i++) {
     int rc = finish_one(i);
     if (rc) return rc;
   }
