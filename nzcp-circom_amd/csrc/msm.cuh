@@ -314,7 +314,8 @@ __global__ __launch_bounds__(64) void msm_redo_kernel(const PackedAffine<F>* __r
       x29_madd(acc, p);
     }
     for (int s = 32; s >= 1; s >>= 1) {
-      const XYZZ<F> q = xyzz_shfl_down(acc, s);
+      XYZZ<F> q = xyzz_shfl_down(acc, s);
+      if (lane >= (uint32_t)s) x29_set_inf(q);   // (see x29_tree_step)
       x29_add(acc, q);
     }
     if (lane == 0) partial[t] = acc;
@@ -339,6 +340,16 @@ template <class F, int WIDTH = 64> __device__ __forceinline__ XYZZ<F> xyzz_shfl_
 #pragma unroll
   for (int i = 0; i < NW; i++) d[i] = __shfl_down(s[i], delta, WIDTH);
   return r;
+}
+// One step of a shuffle tree: lanes [0, d) of a WIDTH-lane group take the value d lanes up.  The other lanes' result
+// is never read, and a shuffle past the group's end returns the lane's OWN value: added blindly that is a doubling, and
+// the whole wavefront then walks both the doubling and the addition path of x29_add (r02 trace: 15-20 us per step
+// against 7.7 us per addition in the reduce kernel) -- they get the point at infinity instead (x29_add returns at once).
+template <class F, int WIDTH = 64>
+__device__ __forceinline__ void x29_tree_step(XYZZ<F>& acc, int d, uint32_t lane_in_group) {
+  XYZZ<F> q = xyzz_shfl_down<F, WIDTH>(acc, d);
+  if (lane_in_group >= (uint32_t)d) x29_set_inf(q);
+  x29_add(acc, q);
 }
 
 // Buckets cut into SEVERAL tasks: bsum[b] = sum of the task partials of bucket b (2 .. light_max
@@ -397,10 +408,7 @@ __global__ __launch_bounds__(kTailThreads) void msm_combine_medium_kernel(const 
         x29_add(acc, sp);
       }
     }
-    for (int d = 8; d >= 1; d >>= 1) {
-      const XYZZ<F> q = xyzz_shfl_down<F, 16>(acc, d);
-      x29_add(acc, q);
-    }
+    for (int d = 8; d >= 1; d >>= 1) x29_tree_step<F, 16>(acc, d, l);
     if (h < count && l == 0) bsum[b] = acc;
   }
 }
@@ -425,10 +433,7 @@ __global__ __launch_bounds__(kTailThreads) void msm_combine_heavy_kernel(const X
       const XYZZ<F> s = partial[t];
       x29_add(acc, s);
     }
-    for (int d = 32; d >= 1; d >>= 1) {
-      const XYZZ<F> q = xyzz_shfl_down(acc, d);
-      x29_add(acc, q);
-    }
+    for (int d = 32; d >= 1; d >>= 1) x29_tree_step<F>(acc, d, lane);
     if (lane == 0) bsum[b] = acc;
   }
 }
@@ -555,10 +560,7 @@ __global__ __launch_bounds__(kTailThreads) void msm_dup_bits_kernel(const XYZZ<F
         msm_mul_small(acc, t, cv);
       }
     }
-    for (int d = 32; d >= 1; d >>= 1) {
-      const XYZZ<F> q = xyzz_shfl_down(acc, d);
-      x29_add(acc, q);
-    }
+    for (int d = 32; d >= 1; d >>= 1) x29_tree_step<F>(acc, d, lane);
   }
   if (lane == 0) dseg[wave] = acc;
 }
@@ -574,10 +576,7 @@ __global__ __launch_bounds__(kTailThreads) void msm_wave_reduce_kernel(const XYZ
   XYZZ<F> p;
   if (i < nin) p = in[(size_t)j * nin + i];
   else x29_set_inf(p);
-  for (int d = 32; d >= 1; d >>= 1) {
-    const XYZZ<F> q = xyzz_shfl_down(p, d);
-    x29_add(p, q);
-  }
+  for (int d = 32; d >= 1; d >>= 1) x29_tree_step<F>(p, d, lane);
   if (lane == 0) out[(size_t)j * nout + blk] = p;
 }
 
