@@ -459,16 +459,25 @@ __global__ __launch_bounds__(kTailThreads) void msm_bucket_reduce_kernel(const X
                                                                const uint32_t* __restrict__ toff,
                                                                uint32_t B, uint32_t nseg, uint32_t rows, uint32_t rps,
                                                                uint32_t W, uint32_t ones, uint32_t salt_bits,
-                                                               uint32_t seg_len, XYZZ<F>* __restrict__ seg) {
+                                                               uint32_t seg_len, uint32_t wave_tree,
+                                                               XYZZ<F>* __restrict__ seg) {
   __builtin_amdgcn_s_setprio(3);   // issue priority over the throughput kernels sharing the SIMD (msm.cuh, kLatencyPrio)
   const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
   if (tid >= rows * nseg) return;
+  // wave_tree (nseg a multiple of 64: a wavefront never straddles two rows): the first level of the tree over the
+  // segment sums happens here, on code that is already running -- seg gets one point per wavefront, and the host
+  // launches one msm_wave_reduce_kernel less (r02 trace, H lane: 104 us for that launch; its 6 steps cost ~50 here)
+  // wave_tree == 2 (nseg a multiple of the workgroup size): the workgroup's wavefront sums are added up through LDS
+  // as well, one point per workgroup
+  __shared__ uint32_t sh_raw[(kTailThreads / 64) * sizeof(XYZZ<F>) / 4];
+  XYZZ<F>* sh = reinterpret_cast<XYZZ<F>*>(sh_raw);
+  const uint32_t out = wave_tree == 2 ? tid / kTailThreads : (wave_tree ? tid >> 6 : tid);
   const uint32_t j = tid / nseg, g = tid % nseg;
   if (j % rps >= W + ones) {                   // dup rows: combined by msm_dup_bits_kernel, not here
     XYZZ<F> z;
     x29_set_inf(z);
-    seg[tid] = z;
-    return;
+    if (!wave_tree || (wave_tree == 1 && (threadIdx.x & 63u) == 0) || threadIdx.x == 0) seg[out] = z;
+    return;                                    // (the whole workgroup is in this row when it uses the barrier below)
   }
   const bool plain = ones && (j % rps == W);   // the "ones" pseudo-window: plain sum of its buckets
   // the salted top window: 2^salt_bits consecutive buckets share the weight (index >> salt_bits) + 1, and a
@@ -493,7 +502,50 @@ __global__ __launch_bounds__(kTailThreads) void msm_bucket_reduce_kernel(const X
     msm_mul_small(m, run, lo);
     x29_add(acc, m);
   }
-  seg[tid] = acc;
+  if (wave_tree) {
+    const uint32_t lane = threadIdx.x & 63u;
+    for (int d = 32; d >= 1; d >>= 1) x29_tree_step<F>(acc, d, lane);
+    if (wave_tree == 2) {
+      if (lane == 0) sh[threadIdx.x >> 6] = acc;
+      __syncthreads();
+      if (threadIdx.x == 0) {
+        for (uint32_t k = 1; k < kTailThreads / 64; k++) x29_add(acc, sh[k]);
+        seg[out] = acc;
+      }
+    } else if (lane == 0) {
+      seg[out] = acc;
+    }
+  } else {
+    seg[tid] = acc;
+  }
+}
+
+// The end of a lane's tree: one workgroup per row adds that row's `cnt` points (strided partial sums per lane, a
+// shuffle tree per wavefront, the four wavefront sums through LDS) and writes the row sum in the canonical format the
+// host folds -- instead of a msm_wave_reduce_kernel launch per factor of 64 plus msm_to_canon_kernel.
+template <class F>
+__global__ __launch_bounds__(kTailThreads) void msm_row_final_kernel(const XYZZ<typename F::Tail>* __restrict__ in, uint32_t cnt,
+                                                                     XYZZ<typename F::CanonOps>* __restrict__ out) {
+  using FT = typename F::Tail;
+  __builtin_amdgcn_s_setprio(3);   // issue priority over the throughput kernels sharing the SIMD (msm.cuh, kLatencyPrio)
+  __shared__ uint32_t sh_raw[(kTailThreads / 64) * sizeof(XYZZ<FT>) / 4];
+  XYZZ<FT>* sh = reinterpret_cast<XYZZ<FT>*>(sh_raw);
+  const uint32_t row = blockIdx.x, lane = threadIdx.x & 63u;
+  XYZZ<FT> p;
+  x29_set_inf(p);
+  for (uint32_t i = threadIdx.x; i < cnt; i += kTailThreads) {
+    const XYZZ<FT> q = in[(size_t)row * cnt + i];
+    x29_add(p, q);
+  }
+  for (int d = 32; d >= 1; d >>= 1) x29_tree_step<FT>(p, d, lane);
+  if (lane == 0) sh[threadIdx.x >> 6] = p;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (uint32_t k = 1; k < kTailThreads / 64; k++) x29_add(p, sh[k]);
+    XYZZ<typename F::CanonOps> r;
+    x29_to_canon<F, typename F::CanonOps>(r, *reinterpret_cast<const XYZZ<F>*>(&p));
+    out[row] = r;
+  }
 }
 
 // Dup rows, step 1: the qualifying non-empty hash buckets of every section of the lane, compacted into
@@ -717,25 +769,30 @@ int msm_launch_lane_t(const MsmGroup& g, MsmWorkspace* ws, MsmLaneWs& ln, const 
     nout_pts += drows;
     if (sd != st) G16_HIP(hipEventRecord(ln.ev_dup_join, sd));
   }
+  const uint32_t wave_tree = (nseg % kTailThreads == 0) ? 2u : ((nseg % 64 == 0) ? 1u : 0u);
   msm_bucket_reduce_kernel<FT><<<(ln.rows * nseg + kTailThreads - 1) / kTailThreads, kTailThreads, 0, st>>>((const TPT*)ln.d_partial, (const TPT*)ln.d_bsum,
                                                                         ln.d_toff, g.B, nseg, ln.rows, g.rps,
                                                                         (uint32_t)g.W, g.ones ? 1u : 0u, g.salt_bits, seg_len,
-                                                                        (TPT*)ln.d_seg);
+                                                                        wave_tree, (TPT*)ln.d_seg);
   mark(2);
-  // tree: d_seg (nseg per row) -> ... -> 1 per row, ping-pong between d_red halves
+  // tree: d_seg (nseg per row, or nseg / 64 after the fused first level) -> ... -> 1 per row, ping-pong between d_red halves
   TPT* cur = (TPT*)ln.d_seg;
-  uint32_t cnt = nseg;
-  TPT* bufs[2] = {(TPT*)ln.d_red, (TPT*)ln.d_red + (size_t)ln.rows * ((nseg + 63) / 64)};
-  int flip = 0;
-  while (cnt > 1) {
-    const uint32_t nout = (cnt + 63) / 64;
-    msm_wave_reduce_kernel<FT><<<dim3((nout + 3) / 4, ln.rows), kTailThreads, 0, st>>>(cur, cnt, bufs[flip], nout);
-    cur = bufs[flip];
-    flip ^= 1;
-    cnt = nout;
+  uint32_t cnt = wave_tree == 2 ? nseg / kTailThreads : (wave_tree ? nseg / 64 : nseg);
+  if (wave_tree == 2 && cnt <= 4096) {
+    msm_row_final_kernel<F><<<ln.rows, kTailThreads, 0, st>>>((const TPT*)cur, cnt, (CPT*)ln.d_canon);
+  } else {
+    TPT* bufs[2] = {(TPT*)ln.d_red, (TPT*)ln.d_red + (size_t)ln.rows * ((nseg + 63) / 64)};
+    int flip = 0;
+    while (cnt > 1) {
+      const uint32_t nout = (cnt + 63) / 64;
+      msm_wave_reduce_kernel<FT><<<dim3((nout + 3) / 4, ln.rows), kTailThreads, 0, st>>>(cur, cnt, bufs[flip], nout);
+      cur = bufs[flip];
+      flip ^= 1;
+      cnt = nout;
+    }
+    G16_HIP(hipGetLastError());
+    msm_to_canon_kernel<F><<<(ln.rows + 63) / 64, 64, 0, st>>>((const PT*)cur, (CPT*)ln.d_canon, ln.rows);
   }
-  G16_HIP(hipGetLastError());
-  msm_to_canon_kernel<F><<<(ln.rows + 63) / 64, 64, 0, st>>>((const PT*)cur, (CPT*)ln.d_canon, ln.rows);
   G16_HIP(hipGetLastError());
   if (g.dup_rows && ln.st_dup) G16_HIP(hipStreamWaitEvent(st, ln.ev_dup_join, 0));
   G16_HIP(hipMemcpyAsync(ln.h_pinned, ln.d_canon, (size_t)nout_pts * sizeof(CPT), hipMemcpyDeviceToHost, st));
