@@ -132,6 +132,10 @@ __global__ __launch_bounds__(256) void k_mul_const(FrM* __restrict__ x, size_t n
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) x[i] = fp_mul(x[i], c);
 }
+__global__ __launch_bounds__(256) void k_stride4(const FrM* __restrict__ in, uint32_t n, FrM* __restrict__ out) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = in[4 * (size_t)i];
+}
 // out[i] = w^i, i < n (each lane: one power by square-and-multiply, then kChunk successive products)
 __global__ __launch_bounds__(256) void k_powers(FrM w, uint32_t n, FrM* __restrict__ out) {
   const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
@@ -145,53 +149,86 @@ __global__ __launch_bounds__(256) void k_powers(FrM w, uint32_t n, FrM* __restri
   }
 }
 
-struct R2Args { FrM beta, gamma, k1, k2, w1; };
-// round 2, per chunk: ratio[i] = num_i / den_i (denominators inverted in one batch per lane), lp[i] = inclusive local
-// prefix product of the ratios, totals[chunk] = the chunk's product
-__global__ __launch_bounds__(256) void k_z_local(const FrM* __restrict__ A, const FrM* __restrict__ B, const FrM* __restrict__ C,
-                                                 const FrM* __restrict__ S1e, const FrM* __restrict__ S2e, const FrM* __restrict__ S3e,
+// Round 2, the grand product.  A wavefront owns kZBlock consecutive rows; lane l takes rows base + 64 k + l, so
+// every load and store of a step is one coalesced 2 KB run (first version: a lane per 64 CONSECUTIVE rows -- fifteen
+// strided passes over the vectors, 4.1 ms of k_z_local + 1.2 ms for the 65 k chunk carries on one workgroup).
+constexpr uint32_t kZSteps = 32;              // rows per lane (r02, round 2 at N = 2^22: 64 -> 16.2 ms, 32 -> 12.0, 16 -> 13.5)
+constexpr uint32_t kZBlock = 64 * kZSteps;
+struct R2Args { FrM beta, gamma, k1, k2, w1, w64; };
+// ratio[i] = num_i / den_i; the denominators of a lane's 64 rows are inverted in one batch (Montgomery's trick works on
+// any set of elements, contiguous or not).  S1..S3: sigma evaluations at the N domain points.
+__global__ __launch_bounds__(256) void k_z_ratio(const FrM* __restrict__ A, const FrM* __restrict__ B, const FrM* __restrict__ C,
+                                                 const FrM* __restrict__ S1, const FrM* __restrict__ S2, const FrM* __restrict__ S3,
                                                  R2Args a, uint32_t n, FrM* __restrict__ num, FrM* __restrict__ den,
-                                                 FrM* __restrict__ pre, FrM* __restrict__ lp, FrM* __restrict__ totals) {
-  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-  const uint32_t lo = t * kChunk;
-  if (lo >= n) return;
-  const uint32_t hi = lo + kChunk < n ? lo + kChunk : n;
-  FrM w = fp_pow_u64(a.w1, lo);
+                                                 FrM* __restrict__ pre) {
+  const uint32_t gt = blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t base = (size_t)(gt >> 6) * kZBlock + (gt & 63u);
+  if (base >= n) return;
+  FrM w = fp_pow_u64(a.w1, base);
   FrM run = fp_one<FrParams>();
-  for (uint32_t i = lo; i < hi; i++) {
+  uint32_t steps = 0;
+  for (size_t i = base; i < n && steps < kZSteps; i += 64, steps++) {
     const FrM bw = fp_mul(a.beta, w);
     const FrM n1 = fp_add(fp_add(A[i], bw), a.gamma);
     const FrM n2 = fp_add(fp_add(B[i], fp_mul(a.k1, bw)), a.gamma);
     const FrM n3 = fp_add(fp_add(C[i], fp_mul(a.k2, bw)), a.gamma);
     num[i] = fp_mul(fp_mul(n1, n2), n3);
-    const FrM d1 = fp_add(fp_add(A[i], fp_mul(a.beta, S1e[4 * (size_t)i])), a.gamma);
-    const FrM d2 = fp_add(fp_add(B[i], fp_mul(a.beta, S2e[4 * (size_t)i])), a.gamma);
-    const FrM d3 = fp_add(fp_add(C[i], fp_mul(a.beta, S3e[4 * (size_t)i])), a.gamma);
+    const FrM d1 = fp_add(fp_add(A[i], fp_mul(a.beta, S1[i])), a.gamma);
+    const FrM d2 = fp_add(fp_add(B[i], fp_mul(a.beta, S2[i])), a.gamma);
+    const FrM d3 = fp_add(fp_add(C[i], fp_mul(a.beta, S3[i])), a.gamma);
     const FrM d = fp_mul(fp_mul(d1, d2), d3);
     den[i] = d;
     pre[i] = run;
     run = fp_mul(run, d);
-    w = fp_mul(w, a.w1);
+    w = fp_mul(w, a.w64);
   }
   FrM inv = fp_inv(run);
-  for (uint32_t i = hi; i-- > lo;) {
+  for (uint32_t k = steps; k-- > 0;) {
+    const size_t i = base + 64 * (size_t)k;
     const FrM di = fp_mul(inv, pre[i]);
     inv = fp_mul(inv, den[i]);
     num[i] = fp_mul(num[i], di);   // the ratio
   }
-  run = fp_one<FrParams>();
-  for (uint32_t i = lo; i < hi; i++) {
-    run = fp_mul(run, num[i]);
-    lp[i] = run;
+}
+__device__ __forceinline__ FrM frm_shfl_up(const FrM& v, int d) {
+  FrM r;
+#pragma unroll
+  for (int i = 0; i < 8; i++) r.v[i] = (uint32_t)__shfl_up((int)v.v[i], d, 64);
+  return r;
+}
+__device__ __forceinline__ FrM frm_shfl(const FrM& v, int lane) {
+  FrM r;
+#pragma unroll
+  for (int i = 0; i < 8; i++) r.v[i] = (uint32_t)__shfl((int)v.v[i], lane, 64);
+  return r;
+}
+// lp[i] = product of the block's ratios up to and including row i (64 rows per step: a shuffle scan across the
+// wavefront, times the running product of the steps before); totals[block] = the block's product
+__global__ __launch_bounds__(256) void k_z_scan(const FrM* __restrict__ ratio, uint32_t n, FrM* __restrict__ lp, FrM* __restrict__ totals) {
+  const uint32_t gt = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t blk = gt >> 6, l = gt & 63u;
+  const size_t base0 = (size_t)blk * kZBlock;
+  if (base0 >= n) return;   // whole wavefronts
+  FrM carry = fp_one<FrParams>();
+  for (uint32_t k = 0; k < kZSteps && base0 + 64 * (size_t)k < n; k++) {
+    const size_t i = base0 + 64 * (size_t)k + l;
+    FrM v = i < n ? ratio[i] : fp_one<FrParams>();
+    for (int d = 1; d < 64; d <<= 1) {
+      const FrM u = frm_shfl_up(v, d);
+      if (l >= (uint32_t)d) v = fp_mul(v, u);
+    }
+    v = fp_mul(v, carry);
+    if (i < n) lp[i] = v;
+    carry = frm_shfl(v, 63);
   }
-  totals[t] = run;
+  if (l == 0) totals[blk] = carry;
 }
 // Z[0] = 1, Z[i + 1] = carry[chunk(i)] * lp[i]
 __global__ __launch_bounds__(256) void k_z_apply(const FrM* __restrict__ lp, const FrM* __restrict__ carry, uint32_t n, FrM* __restrict__ Z) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   if (i == 0) Z[0] = fp_one<FrParams>();
-  if (i + 1 < n) Z[i + 1] = fp_mul(carry[i / kChunk], lp[i]);
+  if (i + 1 < n) Z[i + 1] = fp_mul(carry[i / kZBlock], lp[i]);
 }
 
 // Round 3.  snarkjs evaluates the UNBLINDED polynomials on the 4N subgroup and carries the blinding factors along as
@@ -428,7 +465,7 @@ struct g16_plonk {
   hipStream_t st = nullptr, st2 = nullptr;   // main chain (commitments); the 4N transforms of a round beside its commitments
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   NttTables ntt_n, ntt_4n;
-  FrM* d_ext[8] = {};     // S1 S2 S3 (entries 5..7), 4N evaluations, canonical: round 2 reads them at the N-domain points
+  FrM* d_sig[3] = {};     // S1 S2 S3 at the N domain points (every 4th of the zkey's 4N evaluations), canonical: round 2
   F29* d_ext_l[8] = {};   // Qm Ql Qr Qo Qc S1 S2 S3, 4N evaluations in the lazy format: round 3
   FrM* d_pol[8] = {};     // ... N coefficients
   uint32_t* d_map[3] = {};
@@ -467,7 +504,7 @@ struct g16_plonk {
   std::mutex mu;
   ~g16_plonk() {
     (void)hipSetDevice(device);
-    for (auto p : d_ext) if (p) (void)hipFree(p);
+    for (auto p : d_sig) if (p) (void)hipFree(p);
     for (auto p : d_ext_l) if (p) (void)hipFree(p);
     for (auto p : d_pol) if (p) (void)hipFree(p);
     for (auto p : d_map) if (p) (void)hipFree(p);
@@ -623,13 +660,12 @@ int plonk_create_impl(const uint8_t* zkey, size_t len, int device, g16_plonk* P)
     const uint8_t* src = k < 5 ? s[7 + k].p : s[12].p + (size_t)(k - 5) * polb;
     G16_HIP(hipMalloc(&P->d_pol[k], (size_t)N * 32));
     G16_HIP(hipMalloc(&P->d_ext_l[k], (size_t)N * 4 * sizeof(F29)));
-    FrM* dst = d_stage;
-    if (k >= 5) {   // sigma: round 2 reads the canonical evaluations at the N-domain points
-      G16_HIP(hipMalloc(&P->d_ext[k], (size_t)N * 128));
-      dst = P->d_ext[k];
-    }
     G16_HIP(hipMemcpyAsync(P->d_pol[k], src, (size_t)N * 32, hipMemcpyHostToDevice, st));
-    if (k >= 5) G16_HIP(hipMemcpyAsync(dst, src + (size_t)N * 32, (size_t)N * 128, hipMemcpyHostToDevice, st));
+    if (k >= 5) {   // sigma: round 2 reads the canonical evaluations at the N-domain points (every 4th of the file's 4N)
+      G16_HIP(hipMalloc(&P->d_sig[k - 5], (size_t)N * 32));
+      G16_HIP(hipMemcpyAsync(d_stage, src + (size_t)N * 32, (size_t)N * 128, hipMemcpyHostToDevice, st));
+      k_stride4<<<nblk(N), 256, 0, st>>>(d_stage, N, P->d_sig[k - 5]);
+    }
     // round 3 wants the polynomial on the coset g <w_4N>, not the zkey's subgroup evaluations: transformed here
     if ((rc = coset_fft(P, P->d_pol[k], N, P->d_ext_l[k], st))) return rc;
   }
@@ -939,11 +975,12 @@ int plonk_prove_impl(g16_plonk* P, const uint8_t* wtns, size_t wlen, const uint8
   put_fr_be(tr, beta);
   const FrM gamma = hash_to_fr(tr);
   {
-    R2Args a{beta, gamma, P->k1, P->k2, P->w1};
-    const uint32_t nc = (N + kChunk - 1) / kChunk;
+    R2Args a{beta, gamma, P->k1, P->k2, P->w1, h_pow(P->w1, 64)};
+    const uint32_t nc = (N + kZBlock - 1) / kZBlock;   // blocks = wavefronts
     // num -> d_tmpN (ratios), den -> d_tmpN2, pre -> d_tmpN3, lp -> d_tmpN4
-    k_z_local<<<nblk(nc), 256, 0, st>>>(P->d_A, P->d_B, P->d_C, P->d_ext[5], P->d_ext[6], P->d_ext[7], a, N, P->d_tmpN, P->d_tmpN2,
-                                        P->d_tmpN3, P->d_tmpN4, P->d_tot);
+    k_z_ratio<<<nblk((size_t)nc * 64), 256, 0, st>>>(P->d_A, P->d_B, P->d_C, P->d_sig[0], P->d_sig[1], P->d_sig[2], a, N, P->d_tmpN,
+                                                    P->d_tmpN2, P->d_tmpN3);
+    k_z_scan<<<nblk((size_t)nc * 64), 256, 0, st>>>(P->d_tmpN, N, P->d_tmpN4, P->d_tot);
     k_prefix_prod<<<1, 1024, 0, st>>>(P->d_tot, nc, P->d_tot2, P->d_bad + 2);   // "Copy constraints does not match": read in round 3
     k_z_apply<<<nblk(N), 256, 0, st>>>(P->d_tmpN4, P->d_tot2, N, P->d_Z);
     G16_HIP(hipGetLastError());

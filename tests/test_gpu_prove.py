@@ -145,13 +145,18 @@ def test_multi_device_handle_equals_single(amd, devices):
     mp.close()
 
 
-def test_batch_api(amd):
+@pytest.mark.parametrize("nctx", [None, "1", "2"])
+def test_batch_api(amd, nctx, monkeypatch):
+    """g16_prove_batch pipelines over three proof contexts (G16_BATCH_CTX: sweeps); more proofs than contexts, so that
+    every context is reused; each proof == the oracle's for its own witness."""
     import ctypes as C
+    if nctx:
+        monkeypatch.setenv("G16_BATCH_CTX", nctx)    # read at create
     zk, wt, meta = _golden("tiny")
     n, p, m, seed = meta["n"], meta["p"], meta["m"], meta["seed"]
     zko = f.read_zkey(zk)
     prover = amd.Prover(zk)
-    wts = [wt] + [amd.synth_witness(n, p, m, seed, 500 + i) for i in range(3)]
+    wts = [wt] + [amd.synth_witness(n, p, m, seed, 500 + i) for i in range(6)]
     arr = (C.c_char_p * len(wts))(*wts)
     lens = (C.c_size_t * len(wts))(*[len(x) for x in wts])
     r, s = int(meta["r"]), int(meta["s"])
