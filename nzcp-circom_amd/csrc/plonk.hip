@@ -55,6 +55,17 @@ FrM h_root(int L) {
   return w;
 }
 FrM h_pow(FrM a, uint64_t e) { return fp_pow_u64(a, e); }
+// a^e from the top set bit of e down (fp_pow_u64 walks all 64 bits: 64 squarings for an exponent of 4 bits -- a third
+// of k_suffix_horner, 7 % of k_z_ratio)
+__device__ __forceinline__ FrM frm_pow(const FrM& a, uint64_t e) {
+  if (e == 0) return fp_one<FrParams>();
+  FrM r = a;
+  for (int i = 62 - (int)__clzll((long long)e); i >= 0; i--) {
+    r = fp_sqr(r);
+    if ((e >> i) & 1) r = fp_mul(r, a);
+  }
+  return r;
+}
 
 using namespace transcript;
 
@@ -141,7 +152,7 @@ __global__ __launch_bounds__(256) void k_powers(FrM w, uint32_t n, FrM* __restri
   const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
   const uint32_t lo = t * kChunk;
   if (lo >= n) return;
-  FrM x = fp_pow_u64(w, lo);
+  FrM x = frm_pow(w, lo);
   const uint32_t hi = lo + kChunk < n ? lo + kChunk : n;
   for (uint32_t i = lo; i < hi; i++) {
     out[i] = x;
@@ -164,7 +175,7 @@ __global__ __launch_bounds__(256) void k_z_ratio(const FrM* __restrict__ A, cons
   const uint32_t gt = blockIdx.x * blockDim.x + threadIdx.x;
   const size_t base = (size_t)(gt >> 6) * kZBlock + (gt & 63u);
   if (base >= n) return;
-  FrM w = fp_pow_u64(a.w1, base);
+  FrM w = frm_pow(a.w1, base);
   FrM run = fp_one<FrParams>();
   uint32_t steps = 0;
   for (size_t i = base; i < n && steps < kZSteps; i += 64, steps++) {
@@ -316,7 +327,7 @@ __global__ __launch_bounds__(1024) void k_suffix_horner(const FrM* __restrict__ 
     E[i] = r;
   }
   sm[t] = r;
-  FrM pw = fp_pow_u64(m, B);
+  FrM pw = frm_pow(m, B);
   __syncthreads();
   for (uint32_t d = 1; d < 1024; d <<= 1) {
     const FrM v = t + d < 1024 ? sm[t + d] : fp_zero<FrParams>();
@@ -337,8 +348,8 @@ __global__ __launch_bounds__(1024) void k_suffix_horner(const FrM* __restrict__ 
 __global__ __launch_bounds__(1024) void k_prefix_prod(const FrM* __restrict__ tot, uint32_t nc, FrM* __restrict__ carry,
                                                        uint32_t* __restrict__ flag) {
   __shared__ FrM sm[1024];
-  const uint32_t t = threadIdx.x;
-  const uint32_t B = (nc + 1023) / 1024;
+  const uint32_t t = threadIdx.x, T = blockDim.x;   // T <= 1024, a power of two
+  const uint32_t B = (nc + T - 1) / T;
   const uint32_t lo = t * B < nc ? t * B : nc, hi = lo + B < nc ? lo + B : nc;
   FrM r = fp_one<FrParams>();
   for (uint32_t i = lo; i < hi; i++) {
@@ -347,7 +358,7 @@ __global__ __launch_bounds__(1024) void k_prefix_prod(const FrM* __restrict__ to
   }
   sm[t] = r;
   __syncthreads();
-  for (uint32_t d = 1; d < 1024; d <<= 1) {
+  for (uint32_t d = 1; d < T; d <<= 1) {
     const FrM v = t >= d ? sm[t - d] : fp_one<FrParams>();
     __syncthreads();
     sm[t] = fp_mul(sm[t], v);
@@ -355,7 +366,7 @@ __global__ __launch_bounds__(1024) void k_prefix_prod(const FrM* __restrict__ to
   }
   const FrM c0 = t ? sm[t - 1] : fp_one<FrParams>();
   for (uint32_t i = lo; i < hi; i++) carry[i] = fp_mul(carry[i], c0);
-  if (t == 1023 && !fp_eq(sm[1023], fp_one<FrParams>())) atomicOr(flag, 1u);
+  if (t == T - 1 && !fp_eq(sm[T - 1], fp_one<FrParams>())) atomicOr(flag, 1u);
 }
 __global__ void k_flag_nonzero(const FrM* __restrict__ x, uint32_t* __restrict__ flag) {
   if (threadIdx.x == 0 && blockIdx.x == 0 && !fp_is_zero(x[0])) atomicOr(flag, 1u);
@@ -389,7 +400,7 @@ __global__ __launch_bounds__(1024) void k_suffix_total_multi(EvalJobs jobs, cons
   FrM r = fp_zero<FrParams>();
   for (uint32_t i = hi; i-- > lo;) r = fp_add(h[i], fp_mul(jb.xc, r));
   sm[t] = r;
-  FrM pw = fp_pow_u64(jb.xc, B);
+  FrM pw = frm_pow(jb.xc, B);
   __syncthreads();
   for (uint32_t d = 1; d < 1024; d <<= 1) {
     const FrM v = t + d < 1024 ? sm[t + d] : fp_zero<FrParams>();
@@ -981,7 +992,8 @@ int plonk_prove_impl(g16_plonk* P, const uint8_t* wtns, size_t wlen, const uint8
     k_z_ratio<<<nblk((size_t)nc * 64), 256, 0, st>>>(P->d_A, P->d_B, P->d_C, P->d_sig[0], P->d_sig[1], P->d_sig[2], a, N, P->d_tmpN,
                                                     P->d_tmpN2, P->d_tmpN3);
     k_z_scan<<<nblk((size_t)nc * 64), 256, 0, st>>>(P->d_tmpN, N, P->d_tmpN4, P->d_tot);
-    k_prefix_prod<<<1, 1024, 0, st>>>(P->d_tot, nc, P->d_tot2, P->d_bad + 2);   // "Copy constraints does not match": read in round 3
+    // (a 256-lane workgroup finds a compute unit beside the transforms of the side stream sooner than a 1 024-lane one)
+    k_prefix_prod<<<1, nc > 4096 ? 1024 : 256, 0, st>>>(P->d_tot, nc, P->d_tot2, P->d_bad + 2);   // "Copy constraints does not match": read in round 3
     k_z_apply<<<nblk(N), 256, 0, st>>>(P->d_tmpN4, P->d_tot2, N, P->d_Z);
     G16_HIP(hipGetLastError());
   }
