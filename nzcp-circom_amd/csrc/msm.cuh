@@ -177,6 +177,8 @@ static constexpr uint32_t kTaskChunk = 64;
 static constexpr uint32_t kLightTasks = 3;    // lower bound of the light/other split (sizes the bucket lists)
 static constexpr uint32_t kMediumTasks = 64;  // up to this many partials: a 16-lane group per bucket
 
+// what msm_scan_top_kernel resets / reports for its lane besides the scan (msm_build_queue)
+struct MsmSmallInit { uint32_t *h_stat, *d_class, *d_queue, *d_heavy, *d_medium; };
 // front end + queue construction (msm_g1.hip)
 int msm_front_end(const MsmGroup& g, MsmWorkspace* ws, const Fr* d_scalars, hipStream_t st);
 int msm_build_queue(const MsmGroup& g, MsmWorkspace* ws, MsmLaneWs& ln, hipStream_t st);
@@ -711,7 +713,6 @@ int msm_launch_lane_t(const MsmGroup& g, MsmWorkspace* ws, MsmLaneWs& ln, const 
   }
   if (waves > max_chunks) waves = max_chunks;
   if (waves == 0) waves = 1;
-  G16_HIP(hipMemsetAsync(ln.d_queue, 0, 8, st));
   if (ln.gate) G16_HIP(hipStreamWaitEvent(st, ln.gate, 0));
   G16_HIP(hipEventRecord(ln.ev0, st));
   msm_accumulate_kernel<F><<<(unsigned)waves, 64, 0, st>>>((const PackedAffine<F>*)d_bases, ws->d_sorted, ln.d_toff, nbk,
@@ -720,8 +721,6 @@ int msm_launch_lane_t(const MsmGroup& g, MsmWorkspace* ws, MsmLaneWs& ln, const 
   G16_HIP(hipEventRecord(ln.ev1, st));
   msm_redo_kernel<F><<<64, 64, 0, st>>>((const PackedAffine<F>*)d_bases, ws->d_sorted, ln.point_base, ln.d_task_desc,
                                         ln.d_queue, ln.d_redo, (PT*)ln.d_partial);
-  G16_HIP(hipMemsetAsync(ln.d_heavy, 0, 4, st));
-  G16_HIP(hipMemsetAsync(ln.d_medium, 0, 4, st));
   msm_combine_light_kernel<FT><<<(nbk + kTailThreads - 1) / kTailThreads, kTailThreads, 0, st>>>((const TPT*)ln.d_partial, ln.d_toff, nbk,
                                                               (TPT*)ln.d_bsum, ln.d_heavy, ln.max_heavy, ln.d_medium,
                                                               msm_light_max(ln));

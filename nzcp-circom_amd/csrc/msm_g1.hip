@@ -330,10 +330,15 @@ static __global__ __launch_bounds__(1024) void msm_scan_top_kernel(uint32_t* __r
                                                             const uint32_t* __restrict__ off_base,
                                                             uint32_t* __restrict__ total_a,
                                                             uint32_t* __restrict__ total_b,
-                                                            uint32_t* __restrict__ total_c) {
+                                                            uint32_t* __restrict__ total_c, MsmSmallInit init) {
   __builtin_amdgcn_s_setprio(3);   // issue priority over the throughput kernels sharing the SIMD (msm.cuh, kLatencyPrio)
   __shared__ uint32_t sh_a[1024], sh_b[1024], sh_c[1024];
   const uint32_t tid = threadIdx.x;
+  // the lane's small per-launch state, zeroed here instead of by four hipMemsetAsync (each a ~6 us kernel of its own on
+  // the lane's chain): class counters, queue counters, the medium / heavy bucket lists' counts
+  if (tid < 2 * kRemClasses) init.d_class[tid] = 0;
+  if (tid < 2) init.d_queue[tid] = 0;
+  if (tid == 0) { init.d_heavy[0] = 0; init.d_medium[0] = 0; }
   const uint32_t chunk = (ntiles + 1023) / 1024;
   const uint32_t lo = tid * chunk, hi = (lo + chunk < ntiles) ? lo + chunk : ntiles;
   uint32_t sa = 0, sb = 0, sc = 0;
@@ -353,7 +358,13 @@ static __global__ __launch_bounds__(1024) void msm_scan_top_kernel(uint32_t* __r
     tile_a[k] = pa; tile_b[k] = pb; tile_c[k] = pc;
     pa += va; pb += vb; pc += vc;
   }
-  if (tid == 1023) { *total_a = *off_base + sh_a[1023]; *total_b = sh_b[1023]; *total_c = sh_c[1023]; }
+  if (tid == 1023) {
+    *total_a = *off_base + sh_a[1023]; *total_b = sh_b[1023]; *total_c = sh_c[1023];
+    // end and start of the lane's sorted entries, straight into pinned host memory (read by the NEXT launch, after this
+    // one was collected): two 4-byte copies less on the chain
+    init.h_stat[0] = *off_base + sh_a[1023];
+    init.h_stat[1] = *off_base;
+  }
 }
 
 static __global__ __launch_bounds__(256) void msm_scan_apply_kernel(const uint32_t* __restrict__ cnt, uint32_t nb,
@@ -919,12 +930,10 @@ int msm_build_queue(const MsmGroup& g, MsmWorkspace* ws, MsmLaneWs& ln, hipStrea
   }
   msm_scan_tiles_kernel<<<ntiles, 256, 0, st>>>(cnt, nbk, ln.task_len, ln.d_tile_a, ln.d_tile_b, ln.d_tile_c);
   msm_scan_top_kernel<<<1, 1024, 0, st>>>(ln.d_tile_a, ln.d_tile_b, ln.d_tile_c, ntiles, off_base, ln.d_off + nbk,
-                                          ln.d_toff + nbk, ln.d_foff + nbk);
+                                          ln.d_toff + nbk, ln.d_foff + nbk,
+                                          MsmSmallInit{ln.h_stat, ln.d_class, ln.d_queue, ln.d_heavy, ln.d_medium});
   msm_scan_apply_kernel<<<ntiles, 256, 0, st>>>(cnt, nbk, ln.task_len, ln.d_tile_a, ln.d_tile_b, ln.d_tile_c, off_base,
                                                 ln.d_off, ln.d_toff, ln.d_foff);
-  G16_HIP(hipMemcpyAsync(&ln.h_stat[0], ln.d_off + nbk, 4, hipMemcpyDeviceToHost, st));
-  G16_HIP(hipMemcpyAsync(&ln.h_stat[1], ln.d_off, 4, hipMemcpyDeviceToHost, st));
-  G16_HIP(hipMemsetAsync(ln.d_class, 0, 2 * kRemClasses * 4, st));
   msm_rem_count_kernel<<<(nbk + 255) / 256, 256, 0, st>>>(cnt, nbk, ln.task_len, ln.d_class);
   msm_task_fill_kernel<<<(nbk + 255) / 256, 256, 0, st>>>(ln.d_off, ln.d_toff, ln.d_foff, nbk, ln.task_len, ln.d_task_desc,
                                                           ln.d_qdesc, ln.d_class, ln.d_class + kRemClasses);
