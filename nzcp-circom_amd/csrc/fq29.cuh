@@ -513,6 +513,7 @@ struct Fq29Ops {
   using Canon = Fq;   // canonical twin (fp.cuh)
   using CanonOps = FqOps;
   static constexpr int kAccumWavesPerSimd = 4;   // msm_accumulate: fits 128 VGPRs
+  static constexpr int kReduceThreads = 512;     // msm_bucket_reduce_kernel: workgroup cap (two wavefronts per SIMD)
   static G16_HD T zero() { return f29_zero(); }
   static G16_HD T one() { return f29_one(); }
   static G16_HD bool is_literal_zero(const T& x) { return f29_is_literal_zero(x); }
@@ -536,6 +537,7 @@ struct Fq2x29Ops {
   using Canon = Fq2;
   using CanonOps = Fq2Ops;
   static constexpr int kAccumWavesPerSimd = 2;
+  static constexpr int kReduceThreads = 256;     // one wavefront per SIMD: its accumulators need AGPRs
   static G16_HD T zero() { return T{f29_zero(), f29_zero()}; }
   static G16_HD T one() { return T{f29_one(), f29_zero()}; }
   static G16_HD bool is_literal_zero(const T& x) { return f29_is_literal_zero(x.a) && f29_is_literal_zero(x.b); }

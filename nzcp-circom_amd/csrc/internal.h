@@ -123,6 +123,13 @@ struct MsmGroup {
   // instead of 16.
   int c = 0, Ws = 0, W = 0;     // window bits; scalar windows ceil(254 / c); bucket rows of digit windows per section
   uint32_t pf = 1;
+  // Width of the scalar windows.  Default (wb = c, wx = 0): window j = bits [c j, c j + c), the top one holds what is left of
+  // the 254 bits -- 7 at c = 19, 2 at c = 21, and with ONE row of buckets (pf = Ws) those few digit values are a handful of
+  // buckets that take all n top-window entries: a single bin of the two-level sort, one workgroup sorting n entries (r02: 1.4
+  // ms at n = 2^20; H window 19 / 21 cost 5.5 / 7.1 ms per proof against 4.05 at 20).  Fully precomputed groups therefore
+  // split the 255 bits (254 + the carry of the signed recoding) EVENLY: wx windows of wb + 1 bits, then Ws - wx of wb bits
+  // (c = 20: 8 x 20 + 5 x 19; c = 19: 3 x 19 + 11 x 18), every level of the table at its own window's offset.
+  uint32_t wb = 0, wx = 0;
   uint32_t B = 0;               // buckets per row 2^(c-1)
   uint32_t low_bits = 0, bins = 1;   // bucket = bin << low_bits | low: the two levels of the sort
   bool ones = false;            // extra unweighted row per section for the scalars equal to 1 (witness groups)

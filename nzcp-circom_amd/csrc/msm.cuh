@@ -54,7 +54,11 @@ struct MsmPlan {
   uint32_t W, pf, B, low_bits, bins, rps, rows, ones;
   uint32_t salt_bits;   // see MsmGroup::salt_bits
   uint32_t dup_rows, dup_bits;   // see MsmGroup::dup_rows
+  uint32_t wb, wx;      // scalar window j covers wb + (j < wx) bits from bit j wb + min(j, wx): see MsmGroup::wb
 };
+// the bit offset and width of scalar window j
+__host__ __device__ __forceinline__ uint32_t msm_win_off(const MsmPlan& pl, uint32_t j) { return j * pl.wb + (j < pl.wx ? j : pl.wx); }
+__host__ __device__ __forceinline__ uint32_t msm_win_bits(const MsmPlan& pl, uint32_t j) { return pl.wb + (j < pl.wx ? 1u : 0u); }
 
 // the hash bucket of a scalar value in its section's dup rows
 __host__ __device__ __forceinline__ uint32_t msm_dup_hash(const uint32_t x[8], uint32_t bits) {
@@ -79,8 +83,12 @@ struct MsmLaneWs {
   uint64_t max_tasks = 0;
   uint32_t task_len = 0;             // entries per task in THIS lane (the G2 lane has fewer lanes to fill and cuts shorter)
   uint32_t task_len_min = 0;         // shortest task length a launch may pick (sizes max_tasks)
-  uint32_t* h_stat = nullptr;        // pinned: [0] = end, [1] = start of the lane's sorted entries in the last launch
-  uint32_t seg_len = 0;              // buckets per reduce segment
+  uint32_t* h_stat = nullptr;        // pinned: [0] = end, [1] = start of the lane's sorted entries in the last launch;
+                                     // [2] != 0: that launch needed this many tasks, more than max_tasks; [3] != 0: its
+                                     // medium / heavy bucket lists overflowed (both: msm_collect fails with G16_E_STATE)
+  uint32_t seg_len = 0;              // buckets per reduce segment (a power of two)
+  uint32_t row_pts = 0;              // canonical points the row block of d_canon / h_pinned holds: `rows` row sums, or
+                                     // rows * ngroups * 3 triples when a row is cut into several workgroups (msm_reduce_plan)
   uint32_t* d_off = nullptr;         // [nbk + 1] first sorted entry of a bucket (absolute position in d_sorted)
   uint32_t* d_toff = nullptr;        // [nbk + 1] exclusive scan of ceil(cnt / task_len): first task id of a bucket
   uint32_t* d_foff = nullptr;        // [nbk + 1] exclusive scan of floor(cnt / task_len): full-length tasks
@@ -90,15 +98,15 @@ struct MsmLaneWs {
   uint2* d_task_desc = nullptr;      // by task id
   uint4* d_qdesc = nullptr;          // by queue position: full-length tasks first
   uint32_t* d_class = nullptr;       // [2][kRemClasses]: remainder-class totals and cursors
-  uint32_t* d_queue = nullptr;       // [0] work-queue head of the accumulate kernel, [1] number of flagged tasks
+  uint32_t* d_queue = nullptr;       // [0] work-queue head of the accumulate kernel, [1] number of flagged tasks,
+                                     // [2] != 0: over capacity, no task exists (msm_scan_top_kernel)
   uint32_t* d_redo = nullptr;        // tasks whose fast-path sum met an exceptional case
   void* d_partial = nullptr;         // one XYZZ per task
   void* d_bsum = nullptr;            // one XYZZ per bucket cut into several tasks
   uint32_t* d_heavy = nullptr;       // [0] = count, [1..] = buckets with more than kMediumTasks partials
   uint32_t* d_medium = nullptr;      // the same for light_max < partials <= kMediumTasks
   uint32_t max_heavy = 0;
-  void* d_seg = nullptr;
-  void* d_red = nullptr;
+  void* d_seg = nullptr;             // bucket reduce: one (V, W) pair per workgroup (rows cut into several workgroups)
   void* d_canon = nullptr;           // `rows` canonical XYZZ row sums, then nsec_lane * kDupBitRows chunk sums of the dup rows
   void* d_dseg = nullptr;            // dup rows: per (section, bit, chunk of 64 hash buckets) sums
   void* d_dred = nullptr;            // ... and their tree
@@ -142,13 +150,14 @@ struct MsmWorkspace {
 
 struct U256 { uint32_t v[8]; };
 
-// Buckets per reduce segment: a lane sums its segment with running sums (2 additions per bucket) and weights it
-// with a short double-and-add; shorter segments = more lanes and shorter chains on a latency-bound kernel.
+// Buckets per reduce segment (a power of two): a lane sums its segment with running sums (2 additions per bucket);
+// shorter segments = more lanes and shorter chains on a latency-bound kernel, but a row of more than kReduceMaxThreads
+// segments no longer fits one workgroup (msm_bucket_reduce_kernel).
 // which: 0 = witness group G1 lane, 1 = G2 lane, 2 = dense (H).  G16_SEG_LEN="w,g2,h" overrides (sweeps).
 inline uint32_t msm_seg_len_cfg(int which) {
   struct Cfg { uint32_t v[3]; };
   static const Cfg cfg = [] {   // thread-safe one-time initialisation (two host threads may prove on two handles)
-    Cfg c{{8u, 4u, 8u}};
+    Cfg c{{8u, 8u, 8u}};
     if (const char* e = getenv("G16_SEG_LEN")) {
       int a = 0, b = 0, d = 0;
       const int k = sscanf(e, "%d,%d,%d", &a, &b, &d);
@@ -363,7 +372,7 @@ __global__ __launch_bounds__(kTailThreads) void msm_combine_light_kernel(const X
                                                                XYZZ<F>* __restrict__ bsum,
                                                                uint32_t* __restrict__ heavy, uint32_t max_heavy,
                                                                uint32_t* __restrict__ medium,
-                                                               uint32_t light_max) {
+                                                               uint32_t light_max, uint32_t* __restrict__ h_stat) {
   __builtin_amdgcn_s_setprio(3);   // issue priority over the throughput kernels sharing the SIMD (msm.cuh, kLatencyPrio)
   const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= nbk) return;
@@ -372,7 +381,8 @@ __global__ __launch_bounds__(kTailThreads) void msm_combine_light_kernel(const X
   if (t1 - t0 > light_max) {               // bsum written by the medium / heavy kernel
     uint32_t* list = (t1 - t0 <= kMediumTasks) ? medium : heavy;
     const uint32_t k = atomicAdd(&list[0], 1u);
-    if (k < max_heavy) list[1 + k] = b;    // cannot overflow: max_heavy >= max_tasks / light_max
+    if (k < max_heavy) list[1 + k] = b;    // cannot overflow: max_heavy >= max_tasks / light_max ...
+    else h_stat[3] = 1u;                   // ... and if it ever does, msm_collect reports it instead of a wrong sum
     return;
   }
   XYZZ<F> acc = partial[t0];
@@ -454,99 +464,217 @@ __device__ __forceinline__ XYZZ<F> msm_bucket_value(const XYZZ<F>* __restrict__ 
   return bsum[b];
 }
 
-// seg[j*nseg + g] = sum_{bi in segment g of row j} (bi+1) * S_bi;  ones rows (j % rps == W): plain sum S_bi
+// ---------------------------------------------------------------------------------------------- bucket reduce
+// Row sum = sum_b w(b) S_b over the B buckets of a row, w(b) = b + 1 (digit rows), 1 (the "ones" row), or
+// (b >> salt_bits) + 1 (the salted top window).  A lane owns a SEGMENT of 2^seg_log consecutive buckets and sums it with
+// running sums (A_g = sum_j (j + 1) S_{lo + j}, R_g = sum_j S_{lo + j}: two additions per bucket); the weight of the
+// segment's position, f(g) R_g with f(g) = 2^seg_log g (digit rows) or (g >> sh) + 1 (salted, sh = salt_bits - seg_log),
+// is NOT a multiplication per lane (r02: msm_mul_small(run, lo), up to 19 doublings + additions, was half of this
+// kernel's instructions): with the suffix sums T_g = sum_{g' >= g} R_g',
+//     sum_g f(g) R_g = f(0) T_0 + sum_{g >= 1} (f(g) - f(g - 1)) T_g,
+// and the increments are a constant power of two (2^seg_log at every g, or 1 at every multiple of 2^sh): a suffix SCAN
+// over the lanes (6 shuffle steps in a wavefront, the wavefront totals through LDS), seg_log doublings, one tree.
+// A workgroup covers `wg` consecutive segments of one row.  Rows of at most kReduceMaxThreads segments are one workgroup,
+// which writes the row sum itself (canonical format); longer rows (the dense H-MSM: 2^19 buckets) are cut into workgroups
+// of 256, each writes the pair (V_x, W_x) = (weighted sum relative to its first segment, plain sum), and
+// msm_pairs_fold_kernel + the host (msm_fold_row) finish: sum_x V_x + F(x) W_x is the same problem on nwg points.
+struct MsmReducePlan {
+  uint32_t B, nseg, rows, rps, W, ones, salt_bits;
+  uint32_t seg_log;   // log2(buckets per segment)
+  uint32_t wg;        // segments (= threads) per workgroup: a power of two, 64 .. kReduceMaxThreads
+  uint32_t nwg;       // workgroups per row
+};
+static constexpr uint32_t kReduceMaxThreads = 512;   // G1; a G2 accumulator pair needs the 512 registers of one wavefront per
+                                                     // SIMD: 256-thread workgroups (F::kReduceThreads)
+static constexpr uint32_t kPairGroup = 16;   // msm_pairs_fold_kernel: pairs per lane group (one triple out per group)
+// the weight of pair x of a row cut into workgroups: F(x) = f(x wg), f as in msm_bucket_reduce_kernel.  kind: 0 digit row,
+// 1 ones row, 2 salted top window
+__host__ __device__ inline uint64_t msm_pair_weight(const MsmReducePlan& rp, int kind, uint64_t x) {
+  if (kind == 1) return 1;
+  if (kind == 2) return ((x * rp.wg) >> (rp.salt_bits - rp.seg_log)) + 1;
+  return (x * rp.wg) << rp.seg_log;
+}
+// msm_pairs_fold_kernel: the weights of consecutive pairs of a row differ at every 2^step_log-th pair: digit rows step at
+// every pair; a salted row too when a workgroup spans its 2^sh segments of equal weight, else at every (2^sh / wg)-th pair
+// (the Y of a ones row is not used)
+__host__ __device__ inline uint32_t msm_row_step_log(const MsmReducePlan& rp, int kind) {
+  if (kind != 2) return 0;
+  const uint32_t sh = rp.salt_bits - rp.seg_log;
+  uint32_t wl = 0;
+  while ((1u << wl) < rp.wg) wl++;
+  return sh > wl ? sh - wl : 0u;
+}
+__host__ __device__ inline int msm_row_kind(const MsmReducePlan& rp, uint32_t row) {
+  const uint32_t jr = row % rp.rps;
+  if (rp.ones && jr == rp.W) return 1;
+  if (rp.salt_bits && jr == rp.W - 1) return 2;
+  return 0;   // (dup rows: every pair is the point at infinity, the kind does not matter)
+}
+
+template <class F> __device__ __forceinline__ XYZZ<F> xyzz_shfl(const XYZZ<F>& p, int src) {
+  XYZZ<F> r;
+  constexpr int NW = sizeof(XYZZ<F>) / 4;
+  const uint32_t* s = reinterpret_cast<const uint32_t*>(&p);
+  uint32_t* d = reinterpret_cast<uint32_t*>(&r);
+#pragma unroll
+  for (int i = 0; i < NW; i++) d[i] = __shfl(s[i], src, 64);
+  return r;
+}
+// One step of a suffix scan over the WIDTH lanes of a group: lane l adds the value of lane l + d (nothing past the end)
+template <class F, int WIDTH = 64>
+__device__ __forceinline__ void x29_scan_step(XYZZ<F>& t, int d, uint32_t lane_in_group, uint32_t width) {
+  XYZZ<F> q = xyzz_shfl_down<F, WIDTH>(t, d);
+  if (lane_in_group + (uint32_t)d >= width) x29_set_inf(q);
+  x29_add(t, q);
+}
+
 template <class F>
-__global__ __launch_bounds__(kTailThreads) void msm_bucket_reduce_kernel(const XYZZ<F>* __restrict__ partial,
-                                                               const XYZZ<F>* __restrict__ bsum,
-                                                               const uint32_t* __restrict__ toff,
-                                                               uint32_t B, uint32_t nseg, uint32_t rows, uint32_t rps,
-                                                               uint32_t W, uint32_t ones, uint32_t salt_bits,
-                                                               uint32_t seg_len, uint32_t wave_tree,
-                                                               XYZZ<F>* __restrict__ seg) {
+__global__ __launch_bounds__(F::kReduceThreads) void msm_bucket_reduce_kernel(const XYZZ<F>* __restrict__ partial,
+                                                                    const XYZZ<F>* __restrict__ bsum,
+                                                                    const uint32_t* __restrict__ toff, MsmReducePlan rp,
+                                                                    XYZZ<F>* __restrict__ pairs,
+                                                                    XYZZ<typename F::CanonOps>* __restrict__ canon) {
   __builtin_amdgcn_s_setprio(3);   // issue priority over the throughput kernels sharing the SIMD (msm.cuh, kLatencyPrio)
-  const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
-  if (tid >= rows * nseg) return;
-  // wave_tree (nseg a multiple of 64: a wavefront never straddles two rows): the first level of the tree over the
-  // segment sums happens here, on code that is already running -- seg gets one point per wavefront, and the host
-  // launches one msm_wave_reduce_kernel less (r02 trace, H lane: 104 us for that launch; its 6 steps cost ~50 here)
-  // wave_tree == 2 (nseg a multiple of the workgroup size): the workgroup's wavefront sums are added up through LDS
-  // as well, one point per workgroup
-  __shared__ uint32_t sh_raw[(kTailThreads / 64) * sizeof(XYZZ<F>) / 4];
+  __shared__ uint32_t sh_raw[(F::kReduceThreads / 64) * sizeof(XYZZ<F>) / 4];
   XYZZ<F>* sh = reinterpret_cast<XYZZ<F>*>(sh_raw);
-  const uint32_t out = wave_tree == 2 ? tid / kTailThreads : (wave_tree ? tid >> 6 : tid);
-  const uint32_t j = tid / nseg, g = tid % nseg;
-  if (j % rps >= W + ones) {                   // dup rows: combined by msm_dup_bits_kernel, not here
-    XYZZ<F> z;
-    x29_set_inf(z);
-    if (!wave_tree || (wave_tree == 1 && (threadIdx.x & 63u) == 0) || threadIdx.x == 0) seg[out] = z;
-    return;                                    // (the whole workgroup is in this row when it uses the barrier below)
+  const uint32_t j = blockIdx.x / rp.nwg, x = blockIdx.x % rp.nwg;
+  const uint32_t gl = threadIdx.x, g = x * blockDim.x + gl;      // segment: local to the workgroup, within the row
+  const uint32_t lane = gl & 63u, wv = gl >> 6, nwv = blockDim.x >> 6;
+  const uint32_t jr = j % rp.rps;
+  if (jr >= rp.W + rp.ones) {   // dup rows: combined by msm_dup_bits_kernel, not here (the whole workgroup is in this row)
+    if (gl == 0) {
+      if (rp.nwg == 1) {
+        xyzz_set_inf(canon[j]);
+      } else {
+        XYZZ<F> z;
+        x29_set_inf(z);
+        pairs[2 * (size_t)blockIdx.x] = z;
+        pairs[2 * (size_t)blockIdx.x + 1] = z;
+      }
+    }
+    return;
   }
-  const bool plain = ones && (j % rps == W);   // the "ones" pseudo-window: plain sum of its buckets
-  // the salted top window: 2^salt_bits consecutive buckets share the weight (index >> salt_bits) + 1, and a
-  // segment never straddles two weights (seg_len divides 2^salt_bits)
-  const bool salted = salt_bits && (j % rps == W - 1);
-  const uint32_t lo = g * seg_len;
-  const uint32_t hi = (lo + seg_len < B) ? lo + seg_len : B;
+  const bool plain = rp.ones && jr == rp.W;                  // the "ones" pseudo-window: plain sum of its buckets
+  const bool salted = rp.salt_bits && jr == rp.W - 1;        // 2^salt_bits consecutive buckets share a weight
+  const bool digit = !plain && !salted;
+  // 1. the lane's segment: running sums from its top bucket down
   XYZZ<F> run, acc;
   x29_set_inf(run);
   x29_set_inf(acc);
-  for (uint32_t bi = hi; bi-- > lo;) {
-    const XYZZ<F> s = msm_bucket_value<F>(partial, bsum, toff, j * B + bi);
-    x29_add(run, s);
-    if (!plain && !salted) x29_add(acc, run);
-  }
-  if (plain) {
-    acc = run;
-  } else if (salted) {
-    msm_mul_small(acc, run, (lo >> salt_bits) + 1);
-  } else if (lo != 0) {
-    XYZZ<F> m;
-    msm_mul_small(m, run, lo);
-    x29_add(acc, m);
-  }
-  if (wave_tree) {
-    const uint32_t lane = threadIdx.x & 63u;
-    for (int d = 32; d >= 1; d >>= 1) x29_tree_step<F>(acc, d, lane);
-    if (wave_tree == 2) {
-      if (lane == 0) sh[threadIdx.x >> 6] = acc;
-      __syncthreads();
-      if (threadIdx.x == 0) {
-        for (uint32_t k = 1; k < kTailThreads / 64; k++) x29_add(acc, sh[k]);
-        seg[out] = acc;
-      }
-    } else if (lane == 0) {
-      seg[out] = acc;
+  if (g < rp.nseg) {
+    const uint32_t lo = g << rp.seg_log;
+    const uint32_t hi = (lo + (1u << rp.seg_log) < rp.B) ? lo + (1u << rp.seg_log) : rp.B;
+    for (uint32_t bi = hi; bi-- > lo;) {
+      const XYZZ<F> s = msm_bucket_value<F>(partial, bsum, toff, j * rp.B + bi);
+      x29_add(run, s);
+      if (digit) x29_add(acc, run);
     }
+  }
+  // 2. suffix sums of the segment totals over the workgroup: in the wavefront, then the wavefront totals through LDS
+  for (int d = 1; d < 64; d <<= 1) x29_scan_step<F>(run, d, lane, 64u);
+  XYZZ<F> wtot;   // total of the workgroup (plain sum of its buckets)
+  if (nwv > 1) {
+    if (lane == 0) sh[wv] = run;
+    __syncthreads();
+    XYZZ<F> tw;
+    if (lane < nwv) tw = sh[lane];
+    else x29_set_inf(tw);
+    for (int d = 1; d < (int)nwv; d <<= 1) x29_scan_step<F>(tw, d, lane, nwv);
+    XYZZ<F> above = xyzz_shfl<F>(tw, (int)((wv + 1) & 63u));   // sum of the wavefronts after this one
+    if (wv + 1 >= nwv) x29_set_inf(above);
+    wtot = xyzz_shfl<F>(tw, 0);
+    x29_add(run, above);
+    __syncthreads();   // (sh is reused by the tree below)
   } else {
-    seg[tid] = acc;
+    wtot = xyzz_shfl<F>(run, 0);
+  }
+  // 3. the positions where the weight steps contribute their suffix sum, times the step
+  const uint32_t sh_bits = salted ? rp.salt_bits - rp.seg_log : 0u;
+  const bool sel = !plain && gl >= 1u && (gl & ((1u << sh_bits) - 1u)) == 0u;
+  if (!sel) x29_set_inf(run);
+  if (digit)
+    for (uint32_t k = 0; k < rp.seg_log; k++) x29_dbl(run);
+  x29_add(acc, run);
+  // 4. tree over the workgroup
+  for (int d = 32; d >= 1; d >>= 1) x29_tree_step<F>(acc, d, lane);
+  if (nwv > 1) {
+    if (lane == 0) sh[wv] = acc;
+    __syncthreads();
+    if (wv == 0) {
+      if (lane < nwv) acc = sh[lane];
+      else x29_set_inf(acc);
+      for (int d = (int)nwv >> 1; d >= 1; d >>= 1) x29_tree_step<F>(acc, d, lane);
+    }
+  }
+  if (gl == 0) {
+    if (rp.nwg == 1) {
+      if (!digit) x29_add(acc, wtot);   // f(0) = 1 for the ones row and the salted window, 0 for digit rows
+      XYZZ<typename F::CanonOps> r;
+      x29_to_canon<F, typename F::CanonOps>(r, acc);
+      canon[j] = r;
+    } else {
+      pairs[2 * (size_t)blockIdx.x] = acc;
+      pairs[2 * (size_t)blockIdx.x + 1] = wtot;
+    }
   }
 }
 
-// The end of a lane's tree: one workgroup per row adds that row's `cnt` points (strided partial sums per lane, a
-// shuffle tree per wavefront, the four wavefront sums through LDS) and writes the row sum in the canonical format the
-// host folds -- instead of a msm_wave_reduce_kernel launch per factor of 64 plus msm_to_canon_kernel.
-template <class F>
-__global__ __launch_bounds__(kTailThreads) void msm_row_final_kernel(const XYZZ<typename F::Tail>* __restrict__ in, uint32_t cnt,
-                                                                     XYZZ<typename F::CanonOps>* __restrict__ out) {
-  using FT = typename F::Tail;
+// Rows cut into several workgroups, second step.  A 16-lane group per kPairGroup consecutive pairs (V_x, W_x) of a row,
+// four groups per wavefront (a lone wavefront pays ~9 us per dependent G1 addition, ~20 us per G2 addition, so the short
+// scan and trees of a narrow group beat wider ones):
+//   FINAL (the row has at most kPairGroup pairs -- the G2 lane's rows of two workgroups): the row sum itself,
+//     sum V_x + step * (sum of the suffix sums of W at the pairs where the weight steps) + f(0) * sum W_x, canonical;
+//   else (the H-MSM's one row of 2^19 buckets: 256 pairs): the triple (P = sum V_x, Y = that sum of suffix sums,
+//     Wt = sum W_x) per group; the host adds sum P + step Y + sum_q F(group q) Wt_q (msm_fold_row: a few dozen additions).
+template <class F, bool FINAL>
+__global__ __launch_bounds__(64) void msm_pairs_fold_kernel(const XYZZ<F>* __restrict__ pairs, MsmReducePlan rp,
+                                                            uint32_t ngroups,
+                                                            XYZZ<typename F::CanonOps>* __restrict__ out) {
   __builtin_amdgcn_s_setprio(3);   // issue priority over the throughput kernels sharing the SIMD (msm.cuh, kLatencyPrio)
-  __shared__ uint32_t sh_raw[(kTailThreads / 64) * sizeof(XYZZ<FT>) / 4];
-  XYZZ<FT>* sh = reinterpret_cast<XYZZ<FT>*>(sh_raw);
-  const uint32_t row = blockIdx.x, lane = threadIdx.x & 63u;
-  XYZZ<FT> p;
-  x29_set_inf(p);
-  for (uint32_t i = threadIdx.x; i < cnt; i += kTailThreads) {
-    const XYZZ<FT> q = in[(size_t)row * cnt + i];
-    x29_add(p, q);
+  const uint32_t lane = threadIdx.x, k = lane & (kPairGroup - 1u), nwg = rp.nwg;
+  const uint32_t gid = blockIdx.x * (64u / kPairGroup) + lane / kPairGroup;   // FINAL: the row; else: (row, group)
+  const uint32_t row = FINAL ? gid : gid / ngroups, grp = FINAL ? 0u : gid % ngroups;
+  const bool live = row < rp.rows;
+  const int kind = msm_row_kind(rp, live ? row : 0u);
+  const uint32_t step_log = msm_row_step_log(rp, kind);
+  const uint32_t x = grp * kPairGroup + k;
+  XYZZ<F> v, t;
+  if (live && x < nwg) {
+    v = pairs[2 * ((size_t)row * nwg + x)];
+    t = pairs[2 * ((size_t)row * nwg + x) + 1];
+  } else {
+    x29_set_inf(v);
+    x29_set_inf(t);
   }
-  for (int d = 32; d >= 1; d >>= 1) x29_tree_step<FT>(p, d, lane);
-  if (lane == 0) sh[threadIdx.x >> 6] = p;
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    for (uint32_t k = 1; k < kTailThreads / 64; k++) x29_add(p, sh[k]);
-    XYZZ<typename F::CanonOps> r;
-    x29_to_canon<F, typename F::CanonOps>(r, *reinterpret_cast<const XYZZ<F>*>(&p));
-    out[row] = r;
+  for (int d = 1; d < (int)kPairGroup; d <<= 1) x29_scan_step<F, (int)kPairGroup>(t, d, k, kPairGroup);
+  XYZZ<F> y = t;
+  if (!(kind != 1 && k >= 1u && (x & ((1u << step_log) - 1u)) == 0u)) x29_set_inf(y);
+  if (FINAL) {
+    const uint64_t step = msm_pair_weight(rp, kind, 1ull << step_log) - msm_pair_weight(rp, kind, 0);   // a power of two
+    for (uint64_t m = step; m > 1; m >>= 1) x29_dbl(y);
+    x29_add(v, y);
+    for (int d = (int)kPairGroup >> 1; d >= 1; d >>= 1) x29_tree_step<F, (int)kPairGroup>(v, d, k);
+    if (kind != 0) x29_add(v, t);   // lane k = 0 holds the total of W: f(0) = 1 for the ones row and the salted window
+    if (k == 0 && live) {
+      XYZZ<typename F::CanonOps> r;
+      x29_to_canon<F, typename F::CanonOps>(r, v);
+      out[row] = r;
+    }
+  } else {
+    for (int d = (int)kPairGroup >> 1; d >= 1; d >>= 1) {
+      x29_tree_step<F, (int)kPairGroup>(v, d, k);
+      x29_tree_step<F, (int)kPairGroup>(y, d, k);
+    }
+    if (k == 0 && live) {
+      XYZZ<typename F::CanonOps>* o = out + 3 * ((size_t)row * ngroups + grp);
+      XYZZ<typename F::CanonOps> r;
+      x29_to_canon<F, typename F::CanonOps>(r, v);
+      o[0] = r;
+      x29_to_canon<F, typename F::CanonOps>(r, y);
+      o[1] = r;
+      x29_to_canon<F, typename F::CanonOps>(r, t);
+      o[2] = r;
+    }
   }
 }
 
@@ -672,6 +800,85 @@ __global__ __launch_bounds__(64) void msm_to_canon_kernel(const XYZZ<F>* __restr
   out[i] = r;
 }
 
+// geometry of a lane's bucket reduce (see msm_bucket_reduce_kernel)
+// points per row that leave the device: the row sum (one workgroup per row, or few enough for the FINAL fold), else a
+// triple per pair group
+inline uint32_t msm_row_out_points(const MsmReducePlan& rp) {
+  return rp.nwg <= kPairGroup ? 1u : 3u * ((rp.nwg + kPairGroup - 1) / kPairGroup);
+}
+inline MsmReducePlan msm_reduce_plan(const MsmGroup& g, const MsmLaneWs& ln) {
+  MsmReducePlan rp{};
+  rp.B = g.B; rp.rows = ln.rows; rp.rps = g.rps; rp.W = (uint32_t)g.W; rp.ones = g.ones ? 1u : 0u; rp.salt_bits = g.salt_bits;
+  rp.seg_log = 0;
+  while ((2u << rp.seg_log) <= ln.seg_len) rp.seg_log++;
+  rp.nseg = (g.B + (1u << rp.seg_log) - 1) >> rp.seg_log;
+  uint32_t pad = 64;
+  while (pad < rp.nseg) pad <<= 1;
+  const uint32_t cap = ln.curve == 2 ? (uint32_t)Fq2x29Ops::kReduceThreads : (uint32_t)Fq29Ops::kReduceThreads;
+  if (pad <= cap) { rp.wg = pad; rp.nwg = 1; }
+  else { rp.wg = kTailThreads; rp.nwg = pad / kTailThreads; }
+  return rp;
+}
+// Row sum from the triples (P, Y, Wt) of its pair groups (host; canonical field): sum P + step * sum Y + sum_q F(q G) Wt_q,
+// the last by suffix sums again -- the weights of consecutive groups differ by one constant or not at all.
+template <class FC> inline void xyzz_mul_u64(XYZZ<FC>& r, const XYZZ<FC>& p, uint64_t k) {
+  xyzz_set_inf(r);
+  for (int i = 63; i >= 0; i--) {
+    if (!xyzz_is_inf(r)) xyzz_dbl(r);
+    if ((k >> i) & 1) xyzz_add(r, p);
+  }
+}
+template <class FC>
+inline void msm_fold_row(XYZZ<FC>& out, const XYZZ<FC>* tr, uint32_t ngroups, const MsmReducePlan& rp, int kind) {
+  XYZZ<FC> sp, sy, tw, t;
+  xyzz_set_inf(sp);
+  xyzz_set_inf(sy);
+  for (uint32_t q = 0; q < ngroups; q++) {
+    xyzz_add(sp, tr[3 * q]);
+    xyzz_add(sy, tr[3 * q + 1]);
+  }
+  out = sp;
+  if (kind == 1) {            // ones row: plain sum of everything
+    for (uint32_t q = 0; q < ngroups; q++) xyzz_add(out, tr[3 * q + 2]);
+    return;
+  }
+  // (a salted row whose weight steps are wider than a pair group has Y = infinity: no lane is selected)
+  const uint64_t step = msm_pair_weight(rp, kind, 1ull << msm_row_step_log(rp, kind)) - msm_pair_weight(rp, kind, 0);
+  if (step) {
+    xyzz_mul_u64(t, sy, step);
+    xyzz_add(out, t);
+  }
+  // sum_q w_q Wt_q with w_q = F(q G): = sum_q (w_q - w_{q-1}) TW_q over the suffix sums TW; the differences take at most a
+  // couple of distinct values, one multiplication each
+  uint64_t dv[4] = {0, 0, 0, 0};
+  XYZZ<FC> ds[4];
+  int nd = 0;
+  xyzz_set_inf(tw);
+  for (uint32_t q = ngroups; q-- > 0;) {
+    xyzz_add(tw, tr[3 * q + 2]);
+    const uint64_t wq = msm_pair_weight(rp, kind, (uint64_t)q * kPairGroup);
+    const uint64_t d = q ? wq - msm_pair_weight(rp, kind, (uint64_t)(q - 1) * kPairGroup) : wq;
+    if (!d) continue;
+    int k = 0;
+    while (k < nd && dv[k] != d) k++;
+    if (k == nd) {
+      if (nd == 4) {           // (cannot happen with power-of-two geometry; stay exact anyway)
+        xyzz_mul_u64(t, tw, d);
+        xyzz_add(out, t);
+        continue;
+      }
+      dv[nd] = d;
+      xyzz_set_inf(ds[nd]);
+      nd++;
+    }
+    xyzz_add(ds[k], tw);
+  }
+  for (int k = 0; k < nd; k++) {
+    xyzz_mul_u64(t, ds[k], dv[k]);
+    xyzz_add(out, t);
+  }
+}
+
 // light/heavy split of the combine pass.  A lane sums the partials of a "light" bucket one after the other, so ONE
 // bucket with many partials holds its whole wavefront (and, these kernels being latency-bound, the kernel) for
 // that many sequential additions: r02, real NZCP witness, light_max = 18 -> 17 G2 additions = 1.15 ms for a
@@ -698,8 +905,6 @@ int msm_launch_lane_t(const MsmGroup& g, MsmWorkspace* ws, MsmLaneWs& ln, const 
   if (rc) return rc;
   mark(0);
   const uint32_t nbk = ln.key_hi - ln.key_lo;
-  const uint32_t seg_len = ln.seg_len;
-  const uint32_t nseg = (g.B + seg_len - 1) / seg_len;
   // persistent grid: as many wavefronts as the chip holds for this kernel (4/SIMD G1, 2/SIMD G2), fewer
   // when there is little work
   const uint32_t full_occ = (uint32_t)F::kAccumWavesPerSimd;
@@ -723,7 +928,7 @@ int msm_launch_lane_t(const MsmGroup& g, MsmWorkspace* ws, MsmLaneWs& ln, const 
                                         ln.d_queue, ln.d_redo, (PT*)ln.d_partial);
   msm_combine_light_kernel<FT><<<(nbk + kTailThreads - 1) / kTailThreads, kTailThreads, 0, st>>>((const TPT*)ln.d_partial, ln.d_toff, nbk,
                                                               (TPT*)ln.d_bsum, ln.d_heavy, ln.max_heavy, ln.d_medium,
-                                                              msm_light_max(ln));
+                                                              msm_light_max(ln), ln.h_stat);
   msm_combine_medium_kernel<FT><<<1024, kTailThreads, 0, st>>>((const TPT*)ln.d_partial, ln.d_toff, (TPT*)ln.d_bsum, ln.d_medium,
                                                               ln.max_heavy);
   // one wavefront per heavy bucket, all at once (a real NZCP witness puts thousands of entries into the buckets of
@@ -731,7 +936,7 @@ int msm_launch_lane_t(const MsmGroup& g, MsmWorkspace* ws, MsmLaneWs& ln, const 
   msm_combine_heavy_kernel<FT><<<2048, kTailThreads, 0, st>>>((const TPT*)ln.d_partial, ln.d_toff, (TPT*)ln.d_bsum,
                                                    ln.d_heavy, ln.max_heavy);
   mark(1);
-  uint32_t nout_pts = ln.rows;
+  uint32_t nout_pts = ln.row_pts;
   if (g.dup_rows) {
     // beside the reduce + tree of the digit rows (both are chains of sequential additions on few wavefronts)
     hipStream_t sd = ln.st_dup ? ln.st_dup : st;
@@ -763,34 +968,22 @@ int msm_launch_lane_t(const MsmGroup& g, MsmWorkspace* ws, MsmLaneWs& ln, const 
       dflip ^= 1;
       dcnt = nout;
     }
-    msm_to_canon_kernel<F><<<(drows + 63) / 64, 64, 0, sd>>>((const PT*)dcur, (CPT*)ln.d_canon + ln.rows, drows);
+    msm_to_canon_kernel<F><<<(drows + 63) / 64, 64, 0, sd>>>((const PT*)dcur, (CPT*)ln.d_canon + ln.row_pts, drows);
     G16_HIP(hipGetLastError());
     nout_pts += drows;
     if (sd != st) G16_HIP(hipEventRecord(ln.ev_dup_join, sd));
   }
-  const uint32_t wave_tree = (nseg % kTailThreads == 0) ? 2u : ((nseg % 64 == 0) ? 1u : 0u);
-  msm_bucket_reduce_kernel<FT><<<(ln.rows * nseg + kTailThreads - 1) / kTailThreads, kTailThreads, 0, st>>>((const TPT*)ln.d_partial, (const TPT*)ln.d_bsum,
-                                                                        ln.d_toff, g.B, nseg, ln.rows, g.rps,
-                                                                        (uint32_t)g.W, g.ones ? 1u : 0u, g.salt_bits, seg_len,
-                                                                        wave_tree, (TPT*)ln.d_seg);
+  const MsmReducePlan rp = msm_reduce_plan(g, ln);
+  msm_bucket_reduce_kernel<FT><<<ln.rows * rp.nwg, rp.wg, 0, st>>>((const TPT*)ln.d_partial, (const TPT*)ln.d_bsum, ln.d_toff, rp,
+                                                                   (TPT*)ln.d_seg, (CPT*)ln.d_canon);
   mark(2);
-  // tree: d_seg (nseg per row, or nseg / 64 after the fused first level) -> ... -> 1 per row, ping-pong between d_red halves
-  TPT* cur = (TPT*)ln.d_seg;
-  uint32_t cnt = wave_tree == 2 ? nseg / kTailThreads : (wave_tree ? nseg / 64 : nseg);
-  if (wave_tree == 2 && cnt <= 4096) {
-    msm_row_final_kernel<F><<<ln.rows, kTailThreads, 0, st>>>((const TPT*)cur, cnt, (CPT*)ln.d_canon);
-  } else {
-    TPT* bufs[2] = {(TPT*)ln.d_red, (TPT*)ln.d_red + (size_t)ln.rows * ((nseg + 63) / 64)};
-    int flip = 0;
-    while (cnt > 1) {
-      const uint32_t nout = (cnt + 63) / 64;
-      msm_wave_reduce_kernel<FT><<<dim3((nout + 3) / 4, ln.rows), kTailThreads, 0, st>>>(cur, cnt, bufs[flip], nout);
-      cur = bufs[flip];
-      flip ^= 1;
-      cnt = nout;
-    }
-    G16_HIP(hipGetLastError());
-    msm_to_canon_kernel<F><<<(ln.rows + 63) / 64, 64, 0, st>>>((const PT*)cur, (CPT*)ln.d_canon, ln.rows);
+  if (rp.nwg > 1) {
+    const uint32_t ngroups = (rp.nwg + kPairGroup - 1) / kPairGroup, gpw = 64u / kPairGroup;
+    if (ngroups == 1)
+      msm_pairs_fold_kernel<FT, true><<<(ln.rows + gpw - 1) / gpw, 64, 0, st>>>((const TPT*)ln.d_seg, rp, 1u, (CPT*)ln.d_canon);
+    else
+      msm_pairs_fold_kernel<FT, false><<<(ln.rows * ngroups + gpw - 1) / gpw, 64, 0, st>>>((const TPT*)ln.d_seg, rp, ngroups,
+                                                                                          (CPT*)ln.d_canon);
   }
   G16_HIP(hipGetLastError());
   if (g.dup_rows && ln.st_dup) G16_HIP(hipStreamWaitEvent(st, ln.ev_dup_join, 0));

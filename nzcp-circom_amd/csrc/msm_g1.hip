@@ -153,8 +153,9 @@ static __global__ __launch_bounds__(kBinThreads) void msm_bin_pass_kernel(const 
     }
     uint32_t j = threadIdx.x % Ws;
     for (uint32_t t = 0; t < Ws; t++) {
-      const uint32_t e = msm_extract(sc, (int)(j * (uint32_t)pl.c), pl.c);
-      const int32_t d = (j == Ws - 1) ? (int32_t)e : (int32_t)e - (int32_t)pl.B;   // the top window stays unsigned
+      const uint32_t wj = msm_win_bits(pl, j);
+      const uint32_t e = msm_extract(sc, (int)msm_win_off(pl, j), (int)wj);
+      const int32_t d = (j == Ws - 1) ? (int32_t)e : (int32_t)e - (int32_t)(1u << (wj - 1));   // the top window stays unsigned
       if (d != 0) {
         const uint32_t neg = d < 0 ? 1u : 0u;
         uint32_t bucket = (d < 0 ? (uint32_t)(-d) : (uint32_t)d) - 1u;
@@ -330,7 +331,8 @@ static __global__ __launch_bounds__(1024) void msm_scan_top_kernel(uint32_t* __r
                                                             const uint32_t* __restrict__ off_base,
                                                             uint32_t* __restrict__ total_a,
                                                             uint32_t* __restrict__ total_b,
-                                                            uint32_t* __restrict__ total_c, MsmSmallInit init) {
+                                                            uint32_t* __restrict__ total_c, uint32_t max_tasks,
+                                                            MsmSmallInit init) {
   __builtin_amdgcn_s_setprio(3);   // issue priority over the throughput kernels sharing the SIMD (msm.cuh, kLatencyPrio)
   __shared__ uint32_t sh_a[1024], sh_b[1024], sh_c[1024];
   const uint32_t tid = threadIdx.x;
@@ -338,7 +340,7 @@ static __global__ __launch_bounds__(1024) void msm_scan_top_kernel(uint32_t* __r
   // the lane's chain): class counters, queue counters, the medium / heavy bucket lists' counts
   if (tid < 2 * kRemClasses) init.d_class[tid] = 0;
   if (tid < 2) init.d_queue[tid] = 0;
-  if (tid == 0) { init.d_heavy[0] = 0; init.d_medium[0] = 0; }
+  if (tid == 0) { init.d_heavy[0] = 0; init.d_medium[0] = 0; init.h_stat[3] = 0; }
   const uint32_t chunk = (ntiles + 1023) / 1024;
   const uint32_t lo = tid * chunk, hi = (lo + chunk < ntiles) ? lo + chunk : ntiles;
   uint32_t sa = 0, sb = 0, sc = 0;
@@ -359,7 +361,17 @@ static __global__ __launch_bounds__(1024) void msm_scan_top_kernel(uint32_t* __r
     pa += va; pb += vb; pc += vc;
   }
   if (tid == 1023) {
-    *total_a = *off_base + sh_a[1023]; *total_b = sh_b[1023]; *total_c = sh_c[1023];
+    // The task buffers (task_desc, qdesc, redo, partial) hold max_tasks entries.  Their size is derived from the points
+    // and the SHORTEST task length a launch may pick, so the total cannot exceed it -- but the task length is a
+    // run-time quantity (msm_build_queue), and r02 once got that arithmetic wrong (core dump in g16_g2_multiexp).  So the
+    // invariant is checked where the total is known: over capacity, the lane's kernels see d_queue[2] and do nothing
+    // that indexes by task, and msm_collect turns h_stat[2] into G16_E_STATE.
+    const uint32_t over = sh_b[1023] > max_tasks ? 1u : 0u;
+    init.d_queue[2] = over;
+    init.h_stat[2] = over ? sh_b[1023] : 0u;
+    *total_a = *off_base + sh_a[1023];
+    *total_b = over ? 0u : sh_b[1023];
+    *total_c = over ? 0u : sh_c[1023];
     // end and start of the lane's sorted entries, straight into pinned host memory (read by the NEXT launch, after this
     // one was collected): two 4-byte copies less on the chain
     init.h_stat[0] = *off_base + sh_a[1023];
@@ -372,6 +384,7 @@ static __global__ __launch_bounds__(256) void msm_scan_apply_kernel(const uint32
                                                              const uint32_t* __restrict__ tile_b,
                                                              const uint32_t* __restrict__ tile_c,
                                                              const uint32_t* __restrict__ off_base,
+                                                             const uint32_t* __restrict__ queue,
                                                              uint32_t* __restrict__ off,
                                                              uint32_t* __restrict__ toff,
                                                              uint32_t* __restrict__ foff) {
@@ -397,12 +410,13 @@ static __global__ __launch_bounds__(256) void msm_scan_apply_kernel(const uint32
   }
   uint32_t pa = *off_base + tile_a[blockIdx.x] + sh_a[tid] - sa, pb = tile_b[blockIdx.x] + sh_b[tid] - sb,
            pc = tile_c[blockIdx.x] + sh_c[tid] - sc;
+  const bool over = queue[2] != 0;
 #pragma unroll
   for (int k = 0; k < 8; k++) {
     if (base + k < nb) {
       off[base + k] = pa;
-      toff[base + k] = pb;
-      foff[base + k] = pc;
+      toff[base + k] = over ? 0u : pb;   // over capacity (msm_scan_top_kernel): no bucket has a task
+      foff[base + k] = over ? 0u : pc;
     }
     pa += v[k];
     pb += (v[k] + tl - 1) / tl;
@@ -444,7 +458,7 @@ static __global__ __launch_bounds__(256) void msm_task_fill_kernel(const uint32_
                                                             uint32_t task_len,
                                                             uint2* __restrict__ task_desc, uint4* __restrict__ qdesc,
                                                             const uint32_t* __restrict__ class_total,
-                                                            uint32_t* __restrict__ class_cursor) {
+                                                            uint32_t* __restrict__ class_cursor, uint32_t max_tasks) {
   __builtin_amdgcn_s_setprio(3);   // issue priority over the throughput kernels sharing the SIMD (msm.cuh, kLatencyPrio)
   // remainders: after all the full tasks, by relative-length class (longest first) so that the lanes of a
   // wavefront hold remainders of (nearly) equal length; inside a class the order is whatever the atomics give
@@ -474,18 +488,21 @@ static __global__ __launch_bounds__(256) void msm_task_fill_kernel(const uint32_
   uint32_t fq = foff[b];
   for (uint32_t t = toff[b], e = toff[b + 1]; t < e; t++) {
     const uint32_t len = left < task_len ? left : task_len;
-    task_desc[t] = make_uint2(start, len);
-    qdesc[len == task_len ? fq++ : base[cls] + rank] = make_uint4(start, len, t, 0u);
+    const uint32_t q = len == task_len ? fq++ : base[cls] + rank;
+    if (t < max_tasks && q < max_tasks) {   // (always: the totals were checked by msm_scan_top_kernel)
+      task_desc[t] = make_uint2(start, len);
+      qdesc[q] = make_uint4(start, len, t, 0u);
+    }
     start += len;
     left -= len;
   }
 }
 
 // ====================================================================== host side
-static void msm_make_K(int c, int Ws, U256& K) {
+static void msm_make_K(const MsmPlan& pl, U256& K) {
   for (int i = 0; i < 8; i++) K.v[i] = 0;
-  for (int j = 0; j + 1 < Ws; j++) {
-    const int bit = c * j + c - 1;
+  for (int j = 0; j + 1 < pl.Ws; j++) {
+    const int bit = (int)(msm_win_off(pl, (uint32_t)j) + msm_win_bits(pl, (uint32_t)j)) - 1;
     if (bit < 256) K.v[bit >> 5] |= 1u << (bit & 31);
   }
 }
@@ -508,6 +525,8 @@ static MsmPlan msm_plan_of(const MsmGroup& g) {
   pl.salt_bits = g.salt_bits;
   pl.dup_rows = g.dup_rows;
   pl.dup_bits = g.dup_bits;
+  pl.wb = g.wb;
+  pl.wx = g.wx;
   return pl;
 }
 
@@ -527,14 +546,14 @@ static int msm_precompute_g1(const void* in, void* out, uint32_t n, int ndbl) {
 // Window bits.  Without precomputation: minimise Ws * (n + 2.5 * 2^(c-1)) over c, skipping window sizes whose
 // TOP window holds only 1..5 bits of the 254-bit scalar (its handful of buckets would each collect n / 2^bits
 // entries: r01 sweep, c = 14 made the H-MSM 3x slower).  With full precomputation (one row of buckets):
-// minimise Ws * n + 2.5 * 2^(c-1); the crowded top-window buckets are cut into tasks like any other.
+// minimise Ws * n + 2.5 * 2^(c-1); the windows are then of even width (MsmGroup::wb), no top window is narrow.
 static int choose_c(uint32_t n, bool full_precomp) {
   int best = 13;
   double best_cost = 1e300;
   for (int c = 4; c <= (full_precomp ? 21 : 16); c++) {
     const int Ws = (255 + c - 1) / c;
     const int top_bits = 254 - c * (Ws - 1);
-    if (n >= 4096 && top_bits > 0 && top_bits < 6) continue;
+    if (!full_precomp && n >= 4096 && top_bits > 0 && top_bits < 6) continue;   // (full precomputation: even windows, MsmGroup::wb)
     const double cost = full_precomp ? (double)Ws * (double)n + 2.5 * (double)(1u << (c - 1))
                                      : (double)Ws * ((double)n + 2.5 * (double)(1u << (c - 1)));
     if (cost < best_cost) { best_cost = cost; best = c; }
@@ -552,8 +571,8 @@ static bool is_inf_bytes(const uint8_t* p, size_t psz) {
 }
 
 // upload `count` canonical affine points, convert to the packed lazy format, and (pf > 1) append the levels
-// 2^(ndbl k) * P: dst holds pf * count packed points, level-major
-static int upload_table(int curve, const std::vector<uint8_t>& canon, uint32_t count, uint32_t pf, int ndbl, void** dst) {
+// 2^(ndbl[0] + .. + ndbl[k-1]) * P: dst holds pf * count packed points, level-major
+static int upload_table(int curve, const std::vector<uint8_t>& canon, uint32_t count, uint32_t pf, const std::vector<int>& ndbl, void** dst) {
   const size_t lazy_pt = curve == 2 ? sizeof(PackedAffine<Fq2x29Ops>) : sizeof(PackedAffine<Fq29Ops>);
   void* tmp = nullptr;
   void* tmp2 = nullptr;
@@ -567,7 +586,7 @@ static int upload_table(int curve, const std::vector<uint8_t>& canon, uint32_t c
     void* nxt = (k & 1) ? tmp : tmp2;
     void* d = (uint8_t*)*dst + (size_t)k * count * lazy_pt;
     rc = curve == 2 ? msm_convert_bases_g2(cur, d, count) : msm_convert_bases_g1(cur, d, count);
-    if (!rc && k + 1 < pf) rc = curve == 2 ? msm_precompute_g2(cur, nxt, count, ndbl) : msm_precompute_g1(cur, nxt, count, ndbl);
+    if (!rc && k + 1 < pf) rc = curve == 2 ? msm_precompute_g2(cur, nxt, count, ndbl[k]) : msm_precompute_g1(cur, nxt, count, ndbl[k]);
   }
   (void)hipFree(tmp);
   if (tmp2) (void)hipFree(tmp2);
@@ -657,6 +676,16 @@ int msm_group_create(MsmGroup& g, const MsmSectionIn* secs, int nsec, const MsmC
   g.pf = (uint32_t)((g.Ws + g.W - 1) / g.W);   // drop empty trailing levels (Ws = 16, pf = 5 -> W = 4, pf = 4)
   if ((uint64_t)g.pf * g.n >= 0x7fffffffull) { set_error("msm: too many precomputed bases"); return G16_E_ARG; }
   g.B = 1u << (g.c - 1);
+  g.wb = (uint32_t)g.c;
+  g.wx = 0;
+  {
+    // even windows for a fully precomputed group (see MsmGroup::wb): the top window, unsigned, must stay below c bits
+    const bool uneven_off = getenv("G16_UNIFORM_WINDOWS") && atoi(getenv("G16_UNIFORM_WINDOWS"));
+    if (g.pf == (uint32_t)g.Ws && g.W == 1 && g.Ws > 1 && g.Ws * g.c > 255 && !uneven_off) {
+      g.wb = 255u / (uint32_t)g.Ws;
+      g.wx = 255u - g.wb * (uint32_t)g.Ws;
+    }
+  }
   g.ones = !cfg.dense;
   {
     // salted top window (see MsmGroup::salt_bits): only without window precomputation (a row = one window), when
@@ -722,8 +751,13 @@ int msm_group_create(MsmGroup& g, const MsmSectionIn* secs, int nsec, const MsmC
   G16_HIP(hipMalloc(&g.d_src, (size_t)g.n * 4));
   G16_HIP(hipMemcpy(g.d_src, src.data(), (size_t)g.n * 4, hipMemcpyHostToDevice));
   int rc = G16_OK;
-  if (has_g1) rc = upload_table(1, canon1, g.n, g.pf, g.c * g.W, &g.d_bases);
-  if (!rc && g2_sec >= 0) rc = upload_table(2, canon2, g.sec_n[g2_sec], g.pf, g.c * g.W, &g.d_bases2);
+  std::vector<int> ndbl(g.pf, g.c * g.W);   // level k + 1 = 2^(bits of the windows of level k) * level k
+  if (g.W == 1) {
+    const MsmPlan pl = msm_plan_of(g);
+    for (uint32_t k = 0; k < g.pf; k++) ndbl[k] = (int)msm_win_bits(pl, k);
+  }
+  if (has_g1) rc = upload_table(1, canon1, g.n, g.pf, ndbl, &g.d_bases);
+  if (!rc && g2_sec >= 0) rc = upload_table(2, canon2, g.sec_n[g2_sec], g.pf, ndbl, &g.d_bases2);
   return rc;
 }
 
@@ -755,6 +789,7 @@ static int lane_create(MsmLaneWs& ln, const MsmGroup& g, int curve, uint32_t key
     ln.task_len = (uint32_t)(t < 16 ? 16 : (t > 32 ? 32 : t));
   }
   ln.seg_len = msm_seg_len_cfg(curve == 2 ? 1 : (g.dense ? 2 : 0));
+  while (ln.seg_len & (ln.seg_len - 1)) ln.seg_len &= ln.seg_len - 1;   // a power of two (msm_bucket_reduce_kernel)
   if (g.salt_bits) {   // a segment must not straddle two weights of the salted top window
     while (ln.seg_len > (1u << g.salt_bits) || ((1u << g.salt_bits) % ln.seg_len) != 0) ln.seg_len >>= 1;
     if (ln.seg_len == 0) ln.seg_len = 1;
@@ -768,11 +803,13 @@ static int lane_create(MsmLaneWs& ln, const MsmGroup& g, int curve, uint32_t key
   if (g.task_len_forced) ln.task_len_min = ln.task_len;
   // every non-empty bucket has <= 1 short task + entries / task_len full ones
   ln.max_tasks = nbk + entries / ln.task_len_min + 64;
+  // test hook (tests/test_gpu_edges.py): undersized task buffers, to see the device-side capacity check fire
+  if (const char* e = getenv("G16_TEST_MAX_TASKS"))
+    if (atoll(e) > 0 && (uint64_t)atoll(e) < ln.max_tasks) ln.max_tasks = (uint64_t)atoll(e);
   G16_HIP(hipHostMalloc((void**)&ln.h_stat, 64));
-  ln.h_stat[0] = ln.h_stat[1] = 0;
+  for (int k = 0; k < 16; k++) ln.h_stat[k] = 0;
   const size_t pb = curve == 2 ? sizeof(G2XYZZ29) : sizeof(G1XYZZ29);   // device-side (lazy) points
   const size_t cpb = msm_point_bytes(curve);                             // canonical, host-visible
-  const uint64_t nseg = (g.B + ln.seg_len - 1) / ln.seg_len;
   const size_t ntiles = (size_t)nbk / kScanTile + 2;
   G16_HIP(hipMalloc(&ln.d_off, (nbk + 4) * 4));
   G16_HIP(hipMalloc(&ln.d_toff, (nbk + 4) * 4));
@@ -790,10 +827,11 @@ static int lane_create(MsmLaneWs& ln, const MsmGroup& g, int curve, uint32_t key
   ln.max_heavy = (uint32_t)(ln.max_tasks / kLightTasks + 16);
   G16_HIP(hipMalloc(&ln.d_heavy, ((size_t)ln.max_heavy + 2) * 4));
   G16_HIP(hipMalloc(&ln.d_medium, ((size_t)ln.max_heavy + 2) * 4));
-  G16_HIP(hipMalloc(&ln.d_seg, (size_t)ln.rows * nseg * pb + 256));
-  G16_HIP(hipMalloc(&ln.d_red, 2 * (size_t)ln.rows * ((nseg + 63) / 64) * pb + 256));
+  const MsmReducePlan rp = msm_reduce_plan(g, ln);
+  G16_HIP(hipMalloc(&ln.d_seg, 2 * (size_t)ln.rows * rp.nwg * pb + 256));
   ln.nsec_lane = ln.rows / g.rps;
-  size_t out_pts = ln.rows;
+  ln.row_pts = ln.rows * msm_row_out_points(rp);
+  size_t out_pts = ln.row_pts;
   if (g.dup_rows) {
     const size_t nchunk = ((size_t)1 << g.dup_bits) >> 6, drows = (size_t)ln.nsec_lane * kDupBitRows;
     out_pts += drows;
@@ -821,7 +859,7 @@ static int lane_create(MsmLaneWs& ln, const MsmGroup& g, int curve, uint32_t key
 
 static void lane_destroy(MsmLaneWs& ln) {
   void* ptrs[] = {ln.d_task_desc, ln.d_qdesc, ln.d_class, ln.d_queue, ln.d_redo, ln.d_partial, ln.d_bsum, ln.d_heavy, ln.d_medium,
-                  ln.d_seg, ln.d_red, ln.d_canon, ln.d_off, ln.d_toff, ln.d_foff, ln.d_tile_a, ln.d_tile_b, ln.d_tile_c,
+                  ln.d_seg, ln.d_canon, ln.d_off, ln.d_toff, ln.d_foff, ln.d_tile_a, ln.d_tile_b, ln.d_tile_c,
                   ln.d_dseg, ln.d_dred, ln.d_dcount, ln.d_dlist};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
@@ -882,7 +920,7 @@ int msm_front_end(const MsmGroup& g, MsmWorkspace* ws, const Fr* d_scalars, hipS
   const MsmPlan pl = msm_plan_of(g);
   const uint32_t nrb = g.rows * g.bins;
   U256 K;
-  msm_make_K(g.c, g.Ws, K);
+  msm_make_K(pl, K);
   static const bool trace = getenv("G16_TRACE_HOST") != nullptr;
   auto mark = [&](int k) {
     if (!trace) return;
@@ -930,13 +968,14 @@ int msm_build_queue(const MsmGroup& g, MsmWorkspace* ws, MsmLaneWs& ln, hipStrea
   }
   msm_scan_tiles_kernel<<<ntiles, 256, 0, st>>>(cnt, nbk, ln.task_len, ln.d_tile_a, ln.d_tile_b, ln.d_tile_c);
   msm_scan_top_kernel<<<1, 1024, 0, st>>>(ln.d_tile_a, ln.d_tile_b, ln.d_tile_c, ntiles, off_base, ln.d_off + nbk,
-                                          ln.d_toff + nbk, ln.d_foff + nbk,
+                                          ln.d_toff + nbk, ln.d_foff + nbk, (uint32_t)ln.max_tasks,
                                           MsmSmallInit{ln.h_stat, ln.d_class, ln.d_queue, ln.d_heavy, ln.d_medium});
   msm_scan_apply_kernel<<<ntiles, 256, 0, st>>>(cnt, nbk, ln.task_len, ln.d_tile_a, ln.d_tile_b, ln.d_tile_c, off_base,
-                                                ln.d_off, ln.d_toff, ln.d_foff);
+                                                ln.d_queue, ln.d_off, ln.d_toff, ln.d_foff);
   msm_rem_count_kernel<<<(nbk + 255) / 256, 256, 0, st>>>(cnt, nbk, ln.task_len, ln.d_class);
   msm_task_fill_kernel<<<(nbk + 255) / 256, 256, 0, st>>>(ln.d_off, ln.d_toff, ln.d_foff, nbk, ln.task_len, ln.d_task_desc,
-                                                          ln.d_qdesc, ln.d_class, ln.d_class + kRemClasses);
+                                                          ln.d_qdesc, ln.d_class, ln.d_class + kRemClasses,
+                                                          (uint32_t)ln.max_tasks);
   G16_HIP(hipGetLastError());
   return G16_OK;
 }
@@ -987,28 +1026,53 @@ int msm_collect(const MsmGroup& g, MsmWorkspace* ws, MsmResult* out) {
   for (auto& p : out->g1) xyzz_set_inf(p);
   xyzz_set_inf(out->g2);
   if (!ws->launched || ws->empty) return G16_OK;
+  bool overflow = false;
   for (int l = 0; l < 2; l++) {
     MsmLaneWs& ln = ws->lane[l];
     if (!ln.active) continue;
     G16_HIP(hipEventSynchronize(ln.ev_done));
     (void)hipEventElapsedTime(&ln.last_accum_ms, ln.ev0, ln.ev1);
+    if (ln.h_stat[2] || ln.h_stat[3]) {   // (checked on the device, msm_scan_top_kernel / msm_combine_light_kernel)
+      set_error(ln.h_stat[2] ? "msm: lane " + std::to_string(l) + " needed " + std::to_string(ln.h_stat[2]) +
+                                   " bucket tasks, its buffers hold " + std::to_string(ln.max_tasks)
+                             : "msm: lane " + std::to_string(l) + " overflowed its heavy-bucket list");
+      overflow = true;
+      continue;   // (drain the other lane as well before reporting)
+    }
     if (g.dup_rows && getenv("G16_DEBUG_DUP")) {
       uint32_t dc[4] = {0, 0, 0, 0};
       (void)hipMemcpy(dc, ln.d_dcount, 16, hipMemcpyDeviceToHost);
       fprintf(stderr, "[g16 dup] lane %d: repeated-value buckets per section: %u %u %u\n", l, dc[0], dc[1], dc[2]);
     }
+    const MsmReducePlan rp = msm_reduce_plan(g, ln);
+    const uint32_t ngroups = (rp.nwg + kPairGroup - 1) / kPairGroup;
     if (l == 0) {
       const G1XYZZ* rows = reinterpret_cast<const G1XYZZ*>(ln.h_pinned);
+      std::vector<G1XYZZ> folded;
+      if (rp.nwg > kPairGroup) {   // long rows (the H-MSM's): the device left (P, Y, Wt) triples per pair group
+        folded.resize(ln.rows);
+        for (uint32_t r = 0; r < ln.rows; r++)
+          msm_fold_row<FqOps>(folded[r], rows + (size_t)r * ngroups * 3, ngroups, rp, msm_row_kind(rp, r));
+      }
+      const G1XYZZ* rsum = rp.nwg > kPairGroup ? folded.data() : rows;
       for (int s = 0; s < g.nsec; s++) {
-        msm_combine_windows<FqOps>(out->g1[s], rows + (size_t)s * g.rps, g.W, g.c, g.ones);
-        if (g.dup_rows) msm_add_bit_sums<FqOps>(out->g1[s], rows + ln.rows + (size_t)s * kDupBitRows);
+        msm_combine_windows<FqOps>(out->g1[s], rsum + (size_t)s * g.rps, g.W, g.c, g.ones);
+        if (g.dup_rows) msm_add_bit_sums<FqOps>(out->g1[s], rows + ln.row_pts + (size_t)s * kDupBitRows);
       }
     } else {
       const G2XYZZ* rows = reinterpret_cast<const G2XYZZ*>(ln.h_pinned);
-      msm_combine_windows<Fq2Ops>(out->g2, rows, g.W, g.c, g.ones);
-      if (g.dup_rows) msm_add_bit_sums<Fq2Ops>(out->g2, rows + ln.rows);
+      std::vector<G2XYZZ> folded;
+      if (rp.nwg > kPairGroup) {
+        folded.resize(ln.rows);
+        for (uint32_t r = 0; r < ln.rows; r++)
+          msm_fold_row<Fq2Ops>(folded[r], rows + (size_t)r * ngroups * 3, ngroups, rp, msm_row_kind(rp, r));
+      }
+      const G2XYZZ* rsum = rp.nwg > kPairGroup ? folded.data() : rows;
+      msm_combine_windows<Fq2Ops>(out->g2, rsum, g.W, g.c, g.ones);
+      if (g.dup_rows) msm_add_bit_sums<Fq2Ops>(out->g2, rows + ln.row_pts);
     }
   }
+  if (overflow) return G16_E_STATE;
   return G16_OK;
 }
 

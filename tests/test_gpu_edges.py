@@ -185,3 +185,21 @@ def test_mutated_witness_files_are_refused_or_proved(amd):
     proof, pub = prover.prove(w)      # the handle is still good
     assert len(pub) == prover.info.n_public
     prover.close()
+
+
+def test_task_buffer_overflow_is_an_error_not_a_fault(amd, monkeypatch):
+    """The bucket-task buffers are sized from the points and the shortest task length; the total a launch really needs is
+    known only on the device (it depends on the witness and on the task length picked at run time).  With the buffers
+    forced too small (test hook G16_TEST_MAX_TASKS), the device-side capacity check must turn the launch into
+    G16_E_STATE -- r02 had a core dump here -- and the handle must stay usable."""
+    zkb, wt, _ = amd.synth_setup(3000, 5, 2500, 31)
+    monkeypatch.setenv("G16_TEST_MAX_TASKS", "16")
+    small = amd.Prover(zkb)
+    monkeypatch.delenv("G16_TEST_MAX_TASKS")
+    for _ in range(2):      # twice: the failed launch leaves nothing behind
+        with pytest.raises(amd.G16Error) as e:
+            small.prove(wt, f.le(7), f.le(9))
+        assert e.value.code == -5 and "bucket tasks" in str(e.value), e.value
+    small.close()
+    # the same key and witness on a handle with full-size buffers: the oracle's proof
+    _prove_both(amd, zkb, f.read_wtns(wt)["w"], 7, 9)
