@@ -568,10 +568,11 @@ struct Fq2x29Ops {
 };
 
 
-// Field ops of the latency-bound MSM tail kernels (combine, bucket reduce, trees).  They are the inlined ops: calling
-// ONE out-of-line copy of the products instead (the hypothesis being instruction-cache misses of lone wavefronts on
-// ~80 KB of unrolled G2 code) was measured in r02 and made the G2 tails 10-25 % SLOWER -- a G2 addition simply is
-// ~10 k instructions at the ~11 cycles per instruction a lone wavefront issues at (~46 us).
+// Field ops of the latency-bound MSM tail kernels (combine, bucket reduce, trees).  They are the inlined ops.  Measured and
+// dropped: calling ONE out-of-line copy of the PRODUCTS (r02: G2 tails 10-25 % slower), and calling one copy of the
+// complete point addition / doubling per code object so that the hot code of every tail kernel fits the instruction
+// cache (r03: the kernels shrink from 0.5-1.2 MB to 18-33 KB + a 32 KB / 17 KB pair of functions, and a proof gets
+// 0.2 ms SLOWER: profiles/r03_sweeps.txt).
 struct Fq29TailOps : Fq29Ops {};
 struct Fq2x29TailOps : Fq2x29Ops {};
 

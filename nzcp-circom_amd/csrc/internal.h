@@ -11,6 +11,7 @@
 #include "ec.cuh"
 #include "fq29.cuh"
 
+struct g16_prover;
 namespace g16 {
 
 // ---------------------------------------------------------------- errors (thread-local text)
@@ -26,6 +27,29 @@ const char* get_error();
     }                                                                                      \
   } while (0)
 
+
+// ---------------------------------------------------------------- sharded pipeline inside ONE process (prover.cpp -> multi.cpp)
+// Enqueue-only pieces of the two-phase sharded proof (g16_shard_begin / g16_shard_end are the same pieces with host
+// copies and synchronisation in between, for hosts that exchange the slices themselves: one process per GPU over RCCL).
+// Every call works on the handle's context 0 and returns without waiting for the device unless it says otherwise.
+struct ShardView {
+  int device = 0;
+  hipStream_t st = nullptr;        // the handle's main stream: QAP -> NTT -> (slices arrive) -> join -> H-MSM
+  Fr* d_w = nullptr;               // witness slot (device, nVars words)
+  F29* vec[3] = {nullptr, nullptr, nullptr};   // A, B, C vectors of the context (N lazy elements each)
+  uint32_t lo = 0, hi = 0;         // the handle's range of the domain
+  uint32_t N = 0, nVars = 0;
+};
+int shard_view(g16_prover* p, uint32_t slot, ShardView* out);                 // (allocates the slot)
+// parse + upload + canonicity check of a wtns buffer into `slot`, all behind each other on the main stream
+int shard_upload_witness(g16_prover* p, uint32_t slot, const uint8_t* wtns, size_t len);
+int shard_witness_verdict(g16_prover* p);                                     // after the main stream has drained
+// QAP + odd-coset evaluation of the vectors in `mask`, and the witness MSMs of the handle's point range
+int shard_begin_async(g16_prover* p, uint32_t slot, uint32_t mask);
+// join of [lo, hi), H-MSM, then WAIT and fold: the handle's partial sums
+int shard_end_collect(g16_prover* p, uint8_t partial[G16_PARTIAL_BYTES]);
+// after a failure between begin and end: wait for what begin launched
+void shard_drain(g16_prover* p);
 
 // ---------------------------------------------------------------- trapdoor setup on the device (setup_gpu.hip)
 // out[i] = [k_i] G as affine Montgomery bytes; tbl = host table [nwin][2^wb - 1] of d * 2^(wb j) * G, k in Montgomery form
@@ -130,6 +154,13 @@ struct MsmGroup {
   // split the 255 bits (254 + the carry of the signed recoding) EVENLY: wx windows of wb + 1 bits, then Ws - wx of wb bits
   // (c = 20: 8 x 20 + 5 x 19; c = 19: 3 x 19 + 11 x 18), every level of the table at its own window's offset.
   uint32_t wb = 0, wx = 0;
+  // Optional (G16_WINDOW_ORDER=1; fully precomputed groups of at most 16 windows): the bucket sort's key carries the window
+  // index (4 bits) below the low bucket bits, so a bucket's entries -- and with them every accumulate task -- walk the levels
+  // of the base table in ascending order, and the wavefronts, which start together and take ~two tasks each, gather from the
+  // same one or two 64 MB levels of the 0.87 GB table at any moment (the idea: keep the live slab inside the 256 MB
+  // Infinity Cache; r02: TCC_MISS x 64 B = 1.34 GB per H launch).  r03 measured it: H accumulate 1.042 ms with and 1.041
+  // without, the sort 34 us slower -- the gathers' misses are already hidden behind the integer work.  Off by default.
+  uint32_t wkb = 0;
   uint32_t B = 0;               // buckets per row 2^(c-1)
   uint32_t low_bits = 0, bins = 1;   // bucket = bin << low_bits | low: the two levels of the sort
   bool ones = false;            // extra unweighted row per section for the scalars equal to 1 (witness groups)

@@ -55,6 +55,7 @@ struct MsmPlan {
   uint32_t salt_bits;   // see MsmGroup::salt_bits
   uint32_t dup_rows, dup_bits;   // see MsmGroup::dup_rows
   uint32_t wb, wx;      // scalar window j covers wb + (j < wx) bits from bit j wb + min(j, wx): see MsmGroup::wb
+  uint32_t wkb;         // window bits in the sort key: see MsmGroup::wkb
 };
 // the bit offset and width of scalar window j
 __host__ __device__ __forceinline__ uint32_t msm_win_off(const MsmPlan& pl, uint32_t j) { return j * pl.wb + (j < pl.wx ? j : pl.wx); }
@@ -107,6 +108,8 @@ struct MsmLaneWs {
   uint32_t* d_medium = nullptr;      // the same for light_max < partials <= kMediumTasks
   uint32_t max_heavy = 0;
   void* d_seg = nullptr;             // bucket reduce: one (V, W) pair per workgroup (rows cut into several workgroups)
+  void* d_red = nullptr;             // sparse rows: ping-pong buffers of the tree over the segment sums
+  bool reduce_scan = false;          // dense rows: msm_bucket_reduce_kernel (suffix scans); sparse rows: msm_bucket_reduce_mul_kernel
   void* d_canon = nullptr;           // `rows` canonical XYZZ row sums, then nsec_lane * kDupBitRows chunk sums of the dup rows
   void* d_dseg = nullptr;            // dup rows: per (section, bit, chunk of 64 hash buckets) sums
   void* d_dred = nullptr;            // ... and their tree
@@ -141,6 +144,11 @@ struct MsmWorkspace {
   uint32_t* d_dup_rep = nullptr;     // one of them (global point index), 0xffffffff = none
   uint32_t* d_dup_mixed = nullptr;   // != 0: the bucket holds different values -> not used
   const Fr* d_scalars = nullptr;     // of the running launch
+  // single-pass front end (dense single-row groups, msm_bin_direct_kernel): (row, bin) regions of bin_cap entries in d_tmp
+  bool direct = false;
+  uint32_t bin_cap = 0;
+  uint32_t* h_over = nullptr;        // pinned: != 0 when a bin overflowed in the last launch (msm_collect repeats it two-pass)
+  hipStream_t st_last = nullptr, st2_last = nullptr;   // streams of the running launch (for that repeat)
   MsmLaneWs lane[2];
   hipEvent_t ev_sorted = nullptr;    // sort + scans done: the lanes may start
   hipEvent_t trace_ev[4] = {};       // G16_TRACE_HOST: pass 0, bin scans, pass 1, bin sort
@@ -157,7 +165,7 @@ struct U256 { uint32_t v[8]; };
 inline uint32_t msm_seg_len_cfg(int which) {
   struct Cfg { uint32_t v[3]; };
   static const Cfg cfg = [] {   // thread-safe one-time initialisation (two host threads may prove on two handles)
-    Cfg c{{8u, 8u, 8u}};
+    Cfg c{{8u, 4u, 8u}};
     if (const char* e = getenv("G16_SEG_LEN")) {
       int a = 0, b = 0, d = 0;
       const int k = sscanf(e, "%d,%d,%d", &a, &b, &d);
@@ -462,6 +470,105 @@ __device__ __forceinline__ XYZZ<F> msm_bucket_value(const XYZZ<F>* __restrict__ 
   }
   if (nt == 1) return partial[t0];
   return bsum[b];
+}
+
+// ---------------------------------------------------------------------------------------------- bucket reduce, sparse rows
+// (the witness lanes: most buckets of a row are empty -- a lane whose segment is empty skips its whole weighting, which the
+// scan-based kernel below cannot; r03 measured the scan-based reduce 20-45 % SLOWER on these rows, so they keep r02's kernel)
+// seg[j*nseg + g] = sum_{bi in segment g of row j} (bi+1) * S_bi;  ones rows (j % rps == W): plain sum S_bi
+template <class F>
+__global__ __launch_bounds__(kTailThreads) void msm_bucket_reduce_mul_kernel(const XYZZ<F>* __restrict__ partial,
+                                                               const XYZZ<F>* __restrict__ bsum,
+                                                               const uint32_t* __restrict__ toff,
+                                                               uint32_t B, uint32_t nseg, uint32_t rows, uint32_t rps,
+                                                               uint32_t W, uint32_t ones, uint32_t salt_bits,
+                                                               uint32_t seg_len, uint32_t wave_tree,
+                                                               XYZZ<F>* __restrict__ seg) {
+  __builtin_amdgcn_s_setprio(3);   // issue priority over the throughput kernels sharing the SIMD (msm.cuh, kLatencyPrio)
+  const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
+  if (tid >= rows * nseg) return;
+  // wave_tree (nseg a multiple of 64: a wavefront never straddles two rows): the first level of the tree over the
+  // segment sums happens here, on code that is already running -- seg gets one point per wavefront, and the host
+  // launches one msm_wave_reduce_kernel less (r02 trace, H lane: 104 us for that launch; its 6 steps cost ~50 here)
+  // wave_tree == 2 (nseg a multiple of the workgroup size): the workgroup's wavefront sums are added up through LDS
+  // as well, one point per workgroup
+  __shared__ uint32_t sh_raw[(kTailThreads / 64) * sizeof(XYZZ<F>) / 4];
+  XYZZ<F>* sh = reinterpret_cast<XYZZ<F>*>(sh_raw);
+  const uint32_t out = wave_tree == 2 ? tid / kTailThreads : (wave_tree ? tid >> 6 : tid);
+  const uint32_t j = tid / nseg, g = tid % nseg;
+  if (j % rps >= W + ones) {                   // dup rows: combined by msm_dup_bits_kernel, not here
+    XYZZ<F> z;
+    x29_set_inf(z);
+    if (!wave_tree || (wave_tree == 1 && (threadIdx.x & 63u) == 0) || threadIdx.x == 0) seg[out] = z;
+    return;                                    // (the whole workgroup is in this row when it uses the barrier below)
+  }
+  const bool plain = ones && (j % rps == W);   // the "ones" pseudo-window: plain sum of its buckets
+  // the salted top window: 2^salt_bits consecutive buckets share the weight (index >> salt_bits) + 1, and a
+  // segment never straddles two weights (seg_len divides 2^salt_bits)
+  const bool salted = salt_bits && (j % rps == W - 1);
+  const uint32_t lo = g * seg_len;
+  const uint32_t hi = (lo + seg_len < B) ? lo + seg_len : B;
+  XYZZ<F> run, acc;
+  x29_set_inf(run);
+  x29_set_inf(acc);
+  for (uint32_t bi = hi; bi-- > lo;) {
+    const XYZZ<F> s = msm_bucket_value<F>(partial, bsum, toff, j * B + bi);
+    x29_add(run, s);
+    if (!plain && !salted) x29_add(acc, run);
+  }
+  if (plain) {
+    acc = run;
+  } else if (salted) {
+    msm_mul_small(acc, run, (lo >> salt_bits) + 1);
+  } else if (lo != 0) {
+    XYZZ<F> m;
+    msm_mul_small(m, run, lo);
+    x29_add(acc, m);
+  }
+  if (wave_tree) {
+    const uint32_t lane = threadIdx.x & 63u;
+    for (int d = 32; d >= 1; d >>= 1) x29_tree_step<F>(acc, d, lane);
+    if (wave_tree == 2) {
+      if (lane == 0) sh[threadIdx.x >> 6] = acc;
+      __syncthreads();
+      if (threadIdx.x == 0) {
+        for (uint32_t k = 1; k < kTailThreads / 64; k++) x29_add(acc, sh[k]);
+        seg[out] = acc;
+      }
+    } else if (lane == 0) {
+      seg[out] = acc;
+    }
+  } else {
+    seg[tid] = acc;
+  }
+}
+
+// The end of a lane's tree: one workgroup per row adds that row's `cnt` points (strided partial sums per lane, a
+// shuffle tree per wavefront, the four wavefront sums through LDS) and writes the row sum in the canonical format the
+// host folds -- instead of a msm_wave_reduce_kernel launch per factor of 64 plus msm_to_canon_kernel.
+template <class F>
+__global__ __launch_bounds__(kTailThreads) void msm_row_final_kernel(const XYZZ<typename F::Tail>* __restrict__ in, uint32_t cnt,
+                                                                     XYZZ<typename F::CanonOps>* __restrict__ out) {
+  using FT = typename F::Tail;
+  __builtin_amdgcn_s_setprio(3);   // issue priority over the throughput kernels sharing the SIMD (msm.cuh, kLatencyPrio)
+  __shared__ uint32_t sh_raw[(kTailThreads / 64) * sizeof(XYZZ<FT>) / 4];
+  XYZZ<FT>* sh = reinterpret_cast<XYZZ<FT>*>(sh_raw);
+  const uint32_t row = blockIdx.x, lane = threadIdx.x & 63u;
+  XYZZ<FT> p;
+  x29_set_inf(p);
+  for (uint32_t i = threadIdx.x; i < cnt; i += kTailThreads) {
+    const XYZZ<FT> q = in[(size_t)row * cnt + i];
+    x29_add(p, q);
+  }
+  for (int d = 32; d >= 1; d >>= 1) x29_tree_step<FT>(p, d, lane);
+  if (lane == 0) sh[threadIdx.x >> 6] = p;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (uint32_t k = 1; k < kTailThreads / 64; k++) x29_add(p, sh[k]);
+    XYZZ<typename F::CanonOps> r;
+    x29_to_canon<F, typename F::CanonOps>(r, *reinterpret_cast<const XYZZ<F>*>(&p));
+    out[row] = r;
+  }
 }
 
 // ---------------------------------------------------------------------------------------------- bucket reduce
@@ -814,7 +921,9 @@ inline MsmReducePlan msm_reduce_plan(const MsmGroup& g, const MsmLaneWs& ln) {
   rp.nseg = (g.B + (1u << rp.seg_log) - 1) >> rp.seg_log;
   uint32_t pad = 64;
   while (pad < rp.nseg) pad <<= 1;
-  const uint32_t cap = ln.curve == 2 ? (uint32_t)Fq2x29Ops::kReduceThreads : (uint32_t)Fq29Ops::kReduceThreads;
+  uint32_t cap = ln.curve == 2 ? (uint32_t)Fq2x29Ops::kReduceThreads : (uint32_t)Fq29Ops::kReduceThreads;
+  static const int cap_env = getenv("G16_REDUCE_WG") ? atoi(getenv("G16_REDUCE_WG")) : 0;   // sweeps: 64 / 128 / 256 / 512
+  if (cap_env >= 64 && (uint32_t)cap_env < cap && !(cap_env & (cap_env - 1))) cap = (uint32_t)cap_env;
   if (pad <= cap) { rp.wg = pad; rp.nwg = 1; }
   else { rp.wg = kTailThreads; rp.nwg = pad / kTailThreads; }
   return rp;
@@ -892,7 +1001,7 @@ template <class F>
 int msm_launch_lane_t(const MsmGroup& g, MsmWorkspace* ws, MsmLaneWs& ln, const void* d_bases, hipStream_t st) {
   using PT = XYZZ<F>;
   using CPT = XYZZ<typename F::CanonOps>;
-  using FT = typename F::Tail;   // same element layout; products called instead of inlined where that pays (G2)
+  using FT = typename F::Tail;   // the field ops of the tail kernels: same element layout
   using TPT = XYZZ<FT>;
   static_assert(sizeof(TPT) == sizeof(PT), "tail ops must share the point layout");
   static const bool trace = getenv("G16_TRACE_HOST") != nullptr;
@@ -973,17 +1082,45 @@ int msm_launch_lane_t(const MsmGroup& g, MsmWorkspace* ws, MsmLaneWs& ln, const 
     nout_pts += drows;
     if (sd != st) G16_HIP(hipEventRecord(ln.ev_dup_join, sd));
   }
-  const MsmReducePlan rp = msm_reduce_plan(g, ln);
-  msm_bucket_reduce_kernel<FT><<<ln.rows * rp.nwg, rp.wg, 0, st>>>((const TPT*)ln.d_partial, (const TPT*)ln.d_bsum, ln.d_toff, rp,
-                                                                   (TPT*)ln.d_seg, (CPT*)ln.d_canon);
-  mark(2);
-  if (rp.nwg > 1) {
-    const uint32_t ngroups = (rp.nwg + kPairGroup - 1) / kPairGroup, gpw = 64u / kPairGroup;
-    if (ngroups == 1)
-      msm_pairs_fold_kernel<FT, true><<<(ln.rows + gpw - 1) / gpw, 64, 0, st>>>((const TPT*)ln.d_seg, rp, 1u, (CPT*)ln.d_canon);
-    else
-      msm_pairs_fold_kernel<FT, false><<<(ln.rows * ngroups + gpw - 1) / gpw, 64, 0, st>>>((const TPT*)ln.d_seg, rp, ngroups,
-                                                                                          (CPT*)ln.d_canon);
+  if (ln.reduce_scan) {
+    const MsmReducePlan rp = msm_reduce_plan(g, ln);
+    msm_bucket_reduce_kernel<FT><<<ln.rows * rp.nwg, rp.wg, 0, st>>>((const TPT*)ln.d_partial, (const TPT*)ln.d_bsum, ln.d_toff, rp,
+                                                                     (TPT*)ln.d_seg, (CPT*)ln.d_canon);
+    mark(2);
+    if (rp.nwg > 1) {
+      const uint32_t ngroups = (rp.nwg + kPairGroup - 1) / kPairGroup, gpw = 64u / kPairGroup;
+      if (ngroups == 1)
+        msm_pairs_fold_kernel<FT, true><<<(ln.rows + gpw - 1) / gpw, 64, 0, st>>>((const TPT*)ln.d_seg, rp, 1u, (CPT*)ln.d_canon);
+      else
+        msm_pairs_fold_kernel<FT, false><<<(ln.rows * ngroups + gpw - 1) / gpw, 64, 0, st>>>((const TPT*)ln.d_seg, rp, ngroups,
+                                                                                            (CPT*)ln.d_canon);
+    }
+  } else {
+    const uint32_t seg_len = ln.seg_len;
+    const uint32_t nseg = (g.B + seg_len - 1) / seg_len;
+    const uint32_t wave_tree = (nseg % kTailThreads == 0) ? 2u : ((nseg % 64 == 0) ? 1u : 0u);
+    msm_bucket_reduce_mul_kernel<FT><<<(ln.rows * nseg + kTailThreads - 1) / kTailThreads, kTailThreads, 0, st>>>(
+        (const TPT*)ln.d_partial, (const TPT*)ln.d_bsum, ln.d_toff, g.B, nseg, ln.rows, g.rps, (uint32_t)g.W, g.ones ? 1u : 0u,
+        g.salt_bits, seg_len, wave_tree, (TPT*)ln.d_seg);
+    mark(2);
+    // tree: d_seg (nseg per row, or fewer after the fused first levels) -> ... -> 1 per row, ping-pong between d_red halves
+    TPT* cur = (TPT*)ln.d_seg;
+    uint32_t cnt = wave_tree == 2 ? nseg / kTailThreads : (wave_tree ? nseg / 64 : nseg);
+    if (wave_tree == 2 && cnt <= 4096) {
+      msm_row_final_kernel<F><<<ln.rows, kTailThreads, 0, st>>>((const TPT*)cur, cnt, (CPT*)ln.d_canon);
+    } else {
+      TPT* bufs[2] = {(TPT*)ln.d_red, (TPT*)ln.d_red + (size_t)ln.rows * ((nseg + 63) / 64)};
+      int flip = 0;
+      while (cnt > 1) {
+        const uint32_t nout = (cnt + 63) / 64;
+        msm_wave_reduce_kernel<FT><<<dim3((nout + 3) / 4, ln.rows), kTailThreads, 0, st>>>(cur, cnt, bufs[flip], nout);
+        cur = bufs[flip];
+        flip ^= 1;
+        cnt = nout;
+      }
+      G16_HIP(hipGetLastError());
+      msm_to_canon_kernel<F><<<(ln.rows + 63) / 64, 64, 0, st>>>((const PT*)cur, (CPT*)ln.d_canon, ln.rows);
+    }
   }
   G16_HIP(hipGetLastError());
   if (g.dup_rows && ln.st_dup) G16_HIP(hipStreamWaitEvent(st, ln.ev_dup_join, 0));

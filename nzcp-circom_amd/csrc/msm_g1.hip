@@ -164,7 +164,7 @@ static __global__ __launch_bounds__(kBinThreads) void msm_bin_pass_kernel(const 
         const uint32_t eidx = pl.pf > 1 ? (j / pl.W) * pl.n + i : g;
         const uint32_t rb = (row0 + r) * pl.bins + (bucket >> pl.low_bits);
         const uint32_t pos = atomicAdd(&lds[rb], 1u);
-        if (MODE) tmp[pos] = make_uint2(eidx | (neg << 31), bucket & lowmask);
+        if (MODE) tmp[pos] = make_uint2(eidx | (neg << 31), ((bucket & lowmask) << pl.wkb) | (j & ((1u << pl.wkb) - 1u)));
       }
       j = (j + 1 == Ws) ? 0u : j + 1;
     }
@@ -172,6 +172,67 @@ static __global__ __launch_bounds__(kBinThreads) void msm_bin_pass_kernel(const 
   if (!MODE) {
     __syncthreads();
     for (uint32_t b = threadIdx.x; b < nrb; b += kBinThreads) hist[(size_t)b * chunks + blockIdx.x] = lds[b];
+  }
+}
+
+// Dense single-row groups (the H-MSM, the PLONK commitments: uniform scalars, no value classes): ONE pass instead of
+// count -> two scans -> scatter.  Every (row, bin) owns a fixed-capacity region of tmp; a workgroup counts the digits of
+// its points in LDS, claims a run in every bin with one global atomic per bin, and scatters.  Uniform digits fill the bins
+// evenly (capacity = a multiple of the expected population, MsmWorkspace::bin_cap); a bin that overflows raises
+// over[0] and its entries are dropped -- msm_collect then repeats the launch on the two-pass path, which has no
+// capacity (degenerate scalar vectors: every P_i equal, say).  r02 timeline: pass 0 + its scans were 0.1 ms of the H
+// front end standalone, 0.2 ms in the product schedule, on the critical chain of a proof.
+static __global__ __launch_bounds__(kBinThreads) void msm_bin_direct_kernel(const Fr* __restrict__ scalars,
+                                                              const uint32_t* __restrict__ src, MsmPlan pl, U256 K,
+                                                              uint32_t per, uint32_t cap, uint32_t* __restrict__ bin_cnt,
+                                                              uint32_t* __restrict__ over, uint2* __restrict__ tmp) {
+  __builtin_amdgcn_s_setprio(3);   // issue priority over the throughput kernels sharing the SIMD (msm.cuh, kLatencyPrio)
+  extern __shared__ uint32_t lds[];
+  const uint32_t nrb = pl.rows * pl.bins;
+  for (uint32_t b = threadIdx.x; b < nrb; b += kBinThreads) lds[b] = 0u;
+  __syncthreads();
+  const uint32_t lo = blockIdx.x * per;
+  const uint32_t hi = (lo + per < pl.n) ? lo + per : pl.n;
+  const uint32_t lowmask = (1u << pl.low_bits) - 1;
+  const uint32_t Ws = (uint32_t)pl.Ws;
+  for (int pass = 0; pass < 2; pass++) {
+    for (uint32_t g = lo + threadIdx.x; g < hi; g += kBinThreads) {
+      uint32_t sc[8];
+      (void)msm_load_scalar(scalars, src, g, K, sc);
+      uint32_t j = threadIdx.x % Ws;
+      for (uint32_t t = 0; t < Ws; t++) {
+        const uint32_t wj = msm_win_bits(pl, j);
+        const uint32_t e = msm_extract(sc, (int)msm_win_off(pl, j), (int)wj);
+        const int32_t d = (j == Ws - 1) ? (int32_t)e : (int32_t)e - (int32_t)(1u << (wj - 1));
+        if (d != 0) {
+          const uint32_t neg = d < 0 ? 1u : 0u;
+          uint32_t bucket = (d < 0 ? (uint32_t)(-d) : (uint32_t)d) - 1u;
+          if (pl.salt_bits && j == Ws - 1) bucket = (bucket << pl.salt_bits) | (g & ((1u << pl.salt_bits) - 1));
+          const uint32_t r = pl.pf > 1 ? j % pl.W : j;
+          const uint32_t eidx = pl.pf > 1 ? (j / pl.W) * pl.n + g : g;
+          const uint32_t rb = r * pl.bins + (bucket >> pl.low_bits);
+          const uint32_t pos = atomicAdd(&lds[rb], 1u);
+          if (pass && !(pos & 0x80000000u))
+            tmp[pos] = make_uint2(eidx | (neg << 31), ((bucket & lowmask) << pl.wkb) | (j & ((1u << pl.wkb) - 1u)));
+        }
+        j = (j + 1 == Ws) ? 0u : j + 1;
+      }
+    }
+    __syncthreads();
+    if (!pass) {
+      // claim: lds[b] <- where this workgroup's run of bin b starts (bit 31: the bin is full, its entries are dropped)
+      for (uint32_t b = threadIdx.x; b < nrb; b += kBinThreads) {
+        const uint32_t c = lds[b];
+        uint32_t start = 0x80000000u;
+        if (c) {
+          const uint32_t at = atomicAdd(&bin_cnt[b], c);
+          if (at + c <= cap) start = b * cap + at;
+          else over[0] = 1u;
+        }
+        lds[b] = start;
+      }
+      __syncthreads();
+    }
   }
 }
 
@@ -201,14 +262,15 @@ static __global__ __launch_bounds__(64) void msm_bin_chunkscan_kernel(uint32_t* 
 }
 // exclusive scan of bin_cnt[0, nrb) by one workgroup -> bin_start[0, nrb], bin_start[nrb] = total
 static __global__ __launch_bounds__(1024) void msm_bin_scan_kernel(const uint32_t* __restrict__ bin_cnt, uint32_t nrb,
-                                                            uint32_t* __restrict__ bin_start) {
+                                                            uint32_t* __restrict__ bin_start, uint32_t cap) {
   __builtin_amdgcn_s_setprio(3);   // issue priority over the throughput kernels sharing the SIMD (msm.cuh, kLatencyPrio)
   __shared__ uint32_t sh[1024];
   const uint32_t tid = threadIdx.x;
   const uint32_t per = (nrb + 1023) / 1024;
   const uint32_t lo = tid * per, hi = (lo + per < nrb) ? lo + per : nrb;
+  // (cap: the single-pass front end's bins hold at most `cap` entries; an overflowing launch is repeated, stay in bounds)
   uint32_t s = 0;
-  for (uint32_t k = lo; k < hi; k++) s += bin_cnt[k];
+  for (uint32_t k = lo; k < hi; k++) s += bin_cnt[k] < cap ? bin_cnt[k] : cap;
   sh[tid] = s;
   __syncthreads();
   for (uint32_t d = 1; d < 1024; d <<= 1) {
@@ -220,7 +282,7 @@ static __global__ __launch_bounds__(1024) void msm_bin_scan_kernel(const uint32_
   }
   uint32_t run = sh[tid] - s;
   for (uint32_t k = lo; k < hi; k++) {
-    const uint32_t v = bin_cnt[k];
+    const uint32_t v = bin_cnt[k] < cap ? bin_cnt[k] : cap;
     bin_start[k] = run;
     run += v;
   }
@@ -231,19 +293,29 @@ static __global__ __launch_bounds__(1024) void msm_bin_scan_kernel(const uint32_
 // LDS, write the bucket populations, then scatter the table indices to the bin's OWN contiguous range of the
 // final list (second read of the run comes from L2).
 static constexpr uint32_t kMaxLowBits = 12;
+// direct_cap != 0 (single-pass front end): the bin's entries sit at tmp[rb * direct_cap, + bin_cnt[rb]); the sorted list
+// still starts at bin_start[rb].  pl.wkb != 0: the sort key carries the scalar WINDOW below the low bucket bits, so the
+// entries of a bucket come out ordered by window = by level of the precomputed base table (MsmGroup::wkb).
 static __global__ __launch_bounds__(256) void msm_bin_sort_kernel(const uint2* __restrict__ tmp,
                                                            const uint32_t* __restrict__ bin_start, MsmPlan pl,
+                                                           const uint32_t* __restrict__ bin_cnt, uint32_t direct_cap,
                                                            uint32_t* __restrict__ cnt, uint32_t* __restrict__ sorted) {
   __builtin_amdgcn_s_setprio(3);   // issue priority over the throughput kernels sharing the SIMD (msm.cuh, kLatencyPrio)
   __shared__ uint32_t c[1u << kMaxLowBits];
   __shared__ uint32_t part[256];
   const uint32_t rb = blockIdx.x, tid = threadIdx.x;
-  const uint32_t lo = bin_start[rb], hi = bin_start[rb + 1];
-  const uint32_t nl = 1u << pl.low_bits;
+  const uint32_t out_lo = bin_start[rb];
+  uint32_t lo = out_lo, hi = bin_start[rb + 1];
+  if (direct_cap) {
+    lo = rb * direct_cap;
+    hi = lo + (bin_cnt[rb] < direct_cap ? bin_cnt[rb] : direct_cap);
+  }
+  const uint32_t nb = 1u << pl.low_bits;          // buckets of the bin
+  const uint32_t nl = nb << pl.wkb;               // sort keys
   const uint32_t row = rb / pl.bins, bin = rb % pl.bins;
   uint32_t* __restrict__ cnt_out = cnt + (size_t)row * pl.B + ((size_t)bin << pl.low_bits);
   if (lo == hi) {   // empty bin (e.g. the ones row of a dense scalar vector)
-    for (uint32_t l = tid; l < nl && ((bin << pl.low_bits) + l) < pl.B; l += 256) cnt_out[l] = 0;
+    for (uint32_t l = tid; l < nb && ((bin << pl.low_bits) + l) < pl.B; l += 256) cnt_out[l] = 0;
     return;
   }
   for (uint32_t l = tid; l < nl; l += 256) c[l] = 0;
@@ -271,12 +343,19 @@ static __global__ __launch_bounds__(256) void msm_bin_sort_kernel(const uint2* _
     part[tid] += v;
     __syncthreads();
   }
-  uint32_t run = lo + part[tid] - s;
+  uint32_t run = out_lo + part[tid] - s;
   for (uint32_t l = l0; l < l1; l++) {
     const uint32_t v = c[l];
-    if (((bin << pl.low_bits) + l) < pl.B) cnt_out[l] = v;
     c[l] = run;
     run += v;
+  }
+  __syncthreads();
+  // bucket populations: the keys of bucket b are [b << wkb, (b + 1) << wkb), consecutive in the scanned c
+  for (uint32_t b = tid; b < nb; b += 256) {
+    if (((bin << pl.low_bits) + b) >= pl.B) continue;
+    const uint32_t first = c[b << pl.wkb];
+    const uint32_t next = (b + 1 < nb) ? c[(b + 1) << pl.wkb] : out_lo + (hi - lo);
+    cnt_out[b] = next - first;
   }
   __syncthreads();
   {
@@ -527,6 +606,7 @@ static MsmPlan msm_plan_of(const MsmGroup& g) {
   pl.dup_bits = g.dup_bits;
   pl.wb = g.wb;
   pl.wx = g.wx;
+  pl.wkb = g.wkb;
   return pl;
 }
 
@@ -686,6 +766,11 @@ int msm_group_create(MsmGroup& g, const MsmSectionIn* secs, int nsec, const MsmC
       g.wx = 255u - g.wb * (uint32_t)g.Ws;
     }
   }
+  {
+    // window-ordered buckets (MsmGroup::wkb): opt-in, G16_WINDOW_ORDER=1 -- measured, no gain (see there)
+    const bool on = getenv("G16_WINDOW_ORDER") && atoi(getenv("G16_WINDOW_ORDER"));
+    if (g.pf == (uint32_t)g.Ws && g.W == 1 && g.Ws > 1 && g.Ws <= 16 && on) g.wkb = 4;
+  }
   g.ones = !cfg.dense;
   {
     // salted top window (see MsmGroup::salt_bits): only without window precomputation (a row = one window), when
@@ -719,6 +804,7 @@ int msm_group_create(MsmGroup& g, const MsmSectionIn* secs, int nsec, const MsmC
   }
   g.low_bits = (uint32_t)(g.c - 1) < want_low ? (uint32_t)(g.c - 1) : want_low;
   while (g.low_bits < kMaxLowBits && (uint64_t)g.rows * (g.B >> g.low_bits) > 12288) g.low_bits++;
+  if (g.low_bits + g.wkb > kMaxLowBits) g.wkb = 0;
   g.bins = g.B >> g.low_bits;
   if ((uint64_t)g.rows * g.bins > 12288) { set_error("msm: window bits too large for this group"); return G16_E_ARG; }
   // Task length of the G1 lane (the G2 lane derives its own in lane_create): enough tasks to fill ~256k lanes
@@ -827,10 +913,22 @@ static int lane_create(MsmLaneWs& ln, const MsmGroup& g, int curve, uint32_t key
   ln.max_heavy = (uint32_t)(ln.max_tasks / kLightTasks + 16);
   G16_HIP(hipMalloc(&ln.d_heavy, ((size_t)ln.max_heavy + 2) * 4));
   G16_HIP(hipMalloc(&ln.d_medium, ((size_t)ln.max_heavy + 2) * 4));
+  // dense rows: the scan-based reduce; sparse rows (witness lanes): r02's per-lane weighting (see msm.cuh).  G16_REDUCE_SCAN
+  // = 0 / 1 forces one of them for every lane (sweeps).
+  {
+    static const int force = getenv("G16_REDUCE_SCAN") ? atoi(getenv("G16_REDUCE_SCAN")) : -1;
+    ln.reduce_scan = force < 0 ? g.dense : force != 0;
+  }
   const MsmReducePlan rp = msm_reduce_plan(g, ln);
-  G16_HIP(hipMalloc(&ln.d_seg, 2 * (size_t)ln.rows * rp.nwg * pb + 256));
+  if (ln.reduce_scan) {
+    G16_HIP(hipMalloc(&ln.d_seg, 2 * (size_t)ln.rows * rp.nwg * pb + 256));
+  } else {
+    const uint64_t nseg = (g.B + ln.seg_len - 1) / ln.seg_len;
+    G16_HIP(hipMalloc(&ln.d_seg, (size_t)ln.rows * nseg * pb + 256));
+    G16_HIP(hipMalloc(&ln.d_red, 2 * (size_t)ln.rows * ((nseg + 63) / 64) * pb + 256));
+  }
   ln.nsec_lane = ln.rows / g.rps;
-  ln.row_pts = ln.rows * msm_row_out_points(rp);
+  ln.row_pts = ln.reduce_scan ? ln.rows * msm_row_out_points(rp) : ln.rows;
   size_t out_pts = ln.row_pts;
   if (g.dup_rows) {
     const size_t nchunk = ((size_t)1 << g.dup_bits) >> 6, drows = (size_t)ln.nsec_lane * kDupBitRows;
@@ -859,7 +957,7 @@ static int lane_create(MsmLaneWs& ln, const MsmGroup& g, int curve, uint32_t key
 
 static void lane_destroy(MsmLaneWs& ln) {
   void* ptrs[] = {ln.d_task_desc, ln.d_qdesc, ln.d_class, ln.d_queue, ln.d_redo, ln.d_partial, ln.d_bsum, ln.d_heavy, ln.d_medium,
-                  ln.d_seg, ln.d_canon, ln.d_off, ln.d_toff, ln.d_foff, ln.d_tile_a, ln.d_tile_b, ln.d_tile_c,
+                  ln.d_seg, ln.d_red, ln.d_canon, ln.d_off, ln.d_toff, ln.d_foff, ln.d_tile_a, ln.d_tile_b, ln.d_tile_c,
                   ln.d_dseg, ln.d_dred, ln.d_dcount, ln.d_dlist};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
@@ -882,7 +980,20 @@ int msm_workspace_create(MsmWorkspace** out, const MsmGroup& g) {
   G16_HIP(hipMalloc(&ws->d_hist, ((size_t)g.chunks * nrb + 4) * 4));
   G16_HIP(hipMalloc(&ws->d_bin_cnt, ((size_t)nrb + 4) * 4));
   G16_HIP(hipMalloc(&ws->d_bin_start, ((size_t)nrb + 4) * 4));
-  G16_HIP(hipMalloc(&ws->d_tmp, (g.max_entries + 4) * sizeof(uint2)));
+  {
+    // single-pass front end for dense single-section groups: fixed-capacity bins, 2.5x the average population (even
+    // windows fill the low buckets ~1.4x the average, msm_bin_direct_kernel) + slack for small groups
+    const bool off = getenv("G16_NO_DIRECT_BIN") && atoi(getenv("G16_NO_DIRECT_BIN"));
+    uint64_t cap = (g.max_entries * 5 / 2) / nrb + 1024;
+    if (const char* e = getenv("G16_TEST_BIN_CAP"))   // test hook (tests/test_gpu_edges.py): bins that overflow at once
+      if (atoll(e) > 0) cap = (uint64_t)atoll(e);
+    ws->direct = g.dense && g.nsec == 1 && !g.ones && !g.dup_rows && !off && cap * nrb < 0x7fffffffull;
+    ws->bin_cap = ws->direct ? (uint32_t)cap : 0u;
+  }
+  G16_HIP(hipHostMalloc((void**)&ws->h_over, 64));
+  ws->h_over[0] = 0;
+  const uint64_t tmp_entries = ws->direct ? (uint64_t)ws->bin_cap * nrb : g.max_entries;
+  G16_HIP(hipMalloc(&ws->d_tmp, (tmp_entries + 4) * sizeof(uint2)));
   G16_HIP(hipMalloc(&ws->d_sorted, (g.max_entries + 4) * 4));
   G16_HIP(hipMalloc(&ws->d_cnt, ((size_t)ws->nb + 4) * 4));
   if (g.dup_rows) {
@@ -910,6 +1021,7 @@ void msm_workspace_destroy(MsmWorkspace* ws) {
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   for (auto& ln : ws->lane) lane_destroy(ln);
+  if (ws->h_over) (void)hipHostFree(ws->h_over);
   if (ws->ev_sorted) (void)hipEventDestroy(ws->ev_sorted);
   for (hipEvent_t e : ws->trace_ev)
     if (e) (void)hipEventDestroy(e);
@@ -937,17 +1049,29 @@ int msm_front_end(const MsmGroup& g, MsmWorkspace* ws, const Fr* d_scalars, hipS
     msm_dup_scan_kernel<0><<<(g.n + 255) / 256, 256, 0, st>>>(d_scalars, g.d_src, pl, ws->d_dup_cnt, ws->d_dup_rep, ws->d_dup_mixed);
     msm_dup_scan_kernel<1><<<(g.n + 255) / 256, 256, 0, st>>>(d_scalars, g.d_src, pl, ws->d_dup_cnt, ws->d_dup_rep, ws->d_dup_mixed);
   }
-  msm_bin_pass_kernel<0><<<g.chunks, kBinThreads, lds, st>>>(d_scalars, g.d_src, pl, K, g.per, g.chunks, ws->d_hist, nullptr,
-                                                             ws->d_dup_cnt, ws->d_dup_mixed, nullptr);
-  mark(0);
-  msm_bin_chunkscan_kernel<<<nrb, 64, 0, st>>>(ws->d_hist, g.chunks, ws->d_bin_cnt);
-  msm_bin_scan_kernel<<<1, 1024, 0, st>>>(ws->d_bin_cnt, nrb, ws->d_bin_start);
-  mark(1);
-  msm_bin_pass_kernel<1><<<g.chunks, kBinThreads, lds, st>>>(d_scalars, g.d_src, pl, K, g.per, g.chunks, ws->d_hist,
-                                                             ws->d_bin_start, ws->d_dup_cnt, ws->d_dup_mixed, ws->d_tmp);
-  mark(2);
-  msm_bin_sort_kernel<<<nrb, 256, 0, st>>>(ws->d_tmp, ws->d_bin_start, pl, ws->d_cnt, ws->d_sorted);
-  mark(3);
+  if (ws->direct) {
+    G16_HIP(hipMemsetAsync(ws->d_bin_cnt, 0, (size_t)nrb * 4, st));
+    msm_bin_direct_kernel<<<g.chunks, kBinThreads, lds, st>>>(d_scalars, g.d_src, pl, K, g.per, ws->bin_cap, ws->d_bin_cnt,
+                                                             ws->h_over, ws->d_tmp);
+    mark(0);
+    mark(1);
+    msm_bin_scan_kernel<<<1, 1024, 0, st>>>(ws->d_bin_cnt, nrb, ws->d_bin_start, ws->bin_cap);
+    mark(2);
+    msm_bin_sort_kernel<<<nrb, 256, 0, st>>>(ws->d_tmp, ws->d_bin_start, pl, ws->d_bin_cnt, ws->bin_cap, ws->d_cnt, ws->d_sorted);
+    mark(3);
+  } else {
+    msm_bin_pass_kernel<0><<<g.chunks, kBinThreads, lds, st>>>(d_scalars, g.d_src, pl, K, g.per, g.chunks, ws->d_hist, nullptr,
+                                                               ws->d_dup_cnt, ws->d_dup_mixed, nullptr);
+    mark(0);
+    msm_bin_chunkscan_kernel<<<nrb, 64, 0, st>>>(ws->d_hist, g.chunks, ws->d_bin_cnt);
+    msm_bin_scan_kernel<<<1, 1024, 0, st>>>(ws->d_bin_cnt, nrb, ws->d_bin_start, 0xffffffffu);
+    mark(1);
+    msm_bin_pass_kernel<1><<<g.chunks, kBinThreads, lds, st>>>(d_scalars, g.d_src, pl, K, g.per, g.chunks, ws->d_hist,
+                                                               ws->d_bin_start, ws->d_dup_cnt, ws->d_dup_mixed, ws->d_tmp);
+    mark(2);
+    msm_bin_sort_kernel<<<nrb, 256, 0, st>>>(ws->d_tmp, ws->d_bin_start, pl, nullptr, 0u, ws->d_cnt, ws->d_sorted);
+    mark(3);
+  }
   G16_HIP(hipGetLastError());
   G16_HIP(hipEventRecord(ws->ev_sorted, st));
   return G16_OK;
@@ -982,6 +1106,8 @@ int msm_build_queue(const MsmGroup& g, MsmWorkspace* ws, MsmLaneWs& ln, hipStrea
 
 int msm_launch_front(const MsmGroup& g, MsmWorkspace* ws, const Fr* d_scalars, hipStream_t st) {
   ws->launched = true;
+  ws->st_last = st;
+  ws->st2_last = nullptr;
   ws->empty = (g.n == 0);
   for (auto& ln : ws->lane) ln.last_accum_ms = 0.f;
   if (g.n == 0) return G16_OK;
@@ -992,6 +1118,7 @@ int msm_launch_lanes(const MsmGroup& g, MsmWorkspace* ws, hipStream_t st, hipStr
                      hipEvent_t gate2) {
   if (g.n == 0) return G16_OK;
   int rc;
+  ws->st2_last = st2;
   if (ws->lane[1].active) {
     hipStream_t s2 = st2 ? st2 : st;
     if (s2 != st) G16_HIP(hipStreamWaitEvent(s2, ws->ev_sorted, 0));
@@ -1001,7 +1128,8 @@ int msm_launch_lanes(const MsmGroup& g, MsmWorkspace* ws, hipStream_t st, hipStr
   }
   if (ws->lane[0].active) {
     ws->lane[0].gate = gate1;
-    if ((rc = msm_launch_lane_t<Fq29Ops>(g, ws, ws->lane[0], g.d_bases, st))) return rc;
+    rc = msm_launch_lane_t<Fq29Ops>(g, ws, ws->lane[0], g.d_bases, st);
+    if (rc) return rc;
   }
   return G16_OK;
 }
@@ -1049,12 +1177,12 @@ int msm_collect(const MsmGroup& g, MsmWorkspace* ws, MsmResult* out) {
     if (l == 0) {
       const G1XYZZ* rows = reinterpret_cast<const G1XYZZ*>(ln.h_pinned);
       std::vector<G1XYZZ> folded;
-      if (rp.nwg > kPairGroup) {   // long rows (the H-MSM's): the device left (P, Y, Wt) triples per pair group
+      if (ln.reduce_scan && rp.nwg > kPairGroup) {   // long rows (the H-MSM's): the device left (P, Y, Wt) triples per pair group
         folded.resize(ln.rows);
         for (uint32_t r = 0; r < ln.rows; r++)
           msm_fold_row<FqOps>(folded[r], rows + (size_t)r * ngroups * 3, ngroups, rp, msm_row_kind(rp, r));
       }
-      const G1XYZZ* rsum = rp.nwg > kPairGroup ? folded.data() : rows;
+      const G1XYZZ* rsum = !folded.empty() ? folded.data() : rows;
       for (int s = 0; s < g.nsec; s++) {
         msm_combine_windows<FqOps>(out->g1[s], rsum + (size_t)s * g.rps, g.W, g.c, g.ones);
         if (g.dup_rows) msm_add_bit_sums<FqOps>(out->g1[s], rows + ln.row_pts + (size_t)s * kDupBitRows);
@@ -1062,17 +1190,27 @@ int msm_collect(const MsmGroup& g, MsmWorkspace* ws, MsmResult* out) {
     } else {
       const G2XYZZ* rows = reinterpret_cast<const G2XYZZ*>(ln.h_pinned);
       std::vector<G2XYZZ> folded;
-      if (rp.nwg > kPairGroup) {
+      if (ln.reduce_scan && rp.nwg > kPairGroup) {
         folded.resize(ln.rows);
         for (uint32_t r = 0; r < ln.rows; r++)
           msm_fold_row<Fq2Ops>(folded[r], rows + (size_t)r * ngroups * 3, ngroups, rp, msm_row_kind(rp, r));
       }
-      const G2XYZZ* rsum = rp.nwg > kPairGroup ? folded.data() : rows;
+      const G2XYZZ* rsum = !folded.empty() ? folded.data() : rows;
       msm_combine_windows<Fq2Ops>(out->g2, rsum, g.W, g.c, g.ones);
       if (g.dup_rows) msm_add_bit_sums<Fq2Ops>(out->g2, rows + ln.row_pts);
     }
   }
   if (overflow) return G16_E_STATE;
+  if (ws->direct && ws->h_over[0]) {
+    // a bin of the single-pass front end overflowed (far-from-uniform scalars): its entries were dropped -- repeat the
+    // launch on the two-pass path, which has no capacity, and stay there (the workload is what it is)
+    ws->direct = false;
+    ws->h_over[0] = 0;
+    int rc = msm_launch_front(g, ws, ws->d_scalars, ws->st_last);
+    if (!rc) rc = msm_launch_lanes(g, ws, ws->st_last, ws->st2_last, nullptr, nullptr);
+    if (rc) return rc;
+    return msm_collect(g, ws, out);
+  }
   return G16_OK;
 }
 

@@ -786,6 +786,78 @@ static int device_impl(g16_prover* P, uint32_t slot, Partial& out) {
   return collect_ctx(P, P->ctx[0], out);
 }
 
+// ====================================================================== in-process sharding (multi.cpp)
+namespace g16 {
+
+int shard_view(g16_prover* P, uint32_t slot, ShardView* out) {
+  if (slot >= 65536) { set_error("slot out of range"); return G16_E_ARG; }
+  G16_HIP(hipSetDevice(P->device));
+  if (P->slot_dev.size() <= slot) { P->slot_dev.resize(slot + 1, nullptr); P->slot_pub.resize(slot + 1); }
+  if (!P->slot_dev[slot]) G16_HIP(hipMalloc(&P->slot_dev[slot], (size_t)P->nVars * sizeof(Fr)));
+  ProofCtx& c = P->ctx[0];
+  out->device = P->device;
+  out->st = c.st;
+  out->d_w = P->slot_dev[slot];
+  out->vec[0] = c.d_a; out->vec[1] = c.d_b; out->vec[2] = c.d_c;
+  shard_range(P->N, P->shard_rank, P->shard_count, out->lo, out->hi);
+  out->N = P->N;
+  out->nVars = P->nVars;
+  return G16_OK;
+}
+
+int shard_upload_witness(g16_prover* P, uint32_t slot, const uint8_t* wtns, size_t len) {
+  return stage_impl(P, slot, wtns, len, /*sync=*/false);
+}
+
+int shard_witness_verdict(g16_prover* P) { return witness_ok(P->ctx[0]); }
+
+int shard_begin_async(g16_prover* P, uint32_t slot, uint32_t mask) {
+  if (slot >= P->slot_dev.size() || !P->slot_dev[slot]) { set_error("witness slot not staged"); return G16_E_STATE; }
+  G16_HIP(hipSetDevice(P->device));
+  ProofCtx& c = P->ctx[0];
+  int rc;
+  G16_HIP(hipEventRecord(c.ev[2], c.st));
+  if (mask) {
+    if ((rc = launch_qap_ntt(P, c, P->slot_dev[slot], mask))) return rc;
+  } else {
+    G16_HIP(hipEventRecord(c.ev[3], c.st));
+  }
+  if ((rc = launch_witness_front(P, c, P->slot_dev[slot]))) return rc;
+  if ((rc = launch_witness_lanes(P, c, false))) return rc;
+  P->shard_begun = true;
+  return G16_OK;
+}
+
+int shard_end_collect(g16_prover* P, uint8_t partial[G16_PARTIAL_BYTES]) {
+  if (!P->shard_begun) { set_error("shard_end without shard_begin"); return G16_E_STATE; }
+  P->shard_begun = false;
+  G16_HIP(hipSetDevice(P->device));
+  ProofCtx& c = P->ctx[0];
+  uint32_t lo, hi;
+  shard_range(P->N, P->shard_rank, P->shard_count, lo, hi);
+  int rc = launch_join_h_front(P, c, lo, hi);
+  if (!rc) rc = launch_h_lanes(P, c, false);
+  Partial part;
+  if (rc) {
+    (void)collect_witness_msms(P, c, part);
+    return rc;
+  }
+  if ((rc = collect_ctx(P, c, part))) return rc;
+  memcpy(partial, &part, sizeof(part));
+  return G16_OK;
+}
+
+void shard_drain(g16_prover* P) {
+  if (!P->shard_begun) return;
+  P->shard_begun = false;
+  (void)hipSetDevice(P->device);
+  Partial part;
+  (void)collect_witness_msms(P, P->ctx[0], part);
+  (void)hipStreamSynchronize(P->ctx[0].st);
+}
+
+}  // namespace g16
+
 // ====================================================================== C ABI
 extern "C" {
 

@@ -203,3 +203,21 @@ def test_task_buffer_overflow_is_an_error_not_a_fault(amd, monkeypatch):
     small.close()
     # the same key and witness on a handle with full-size buffers: the oracle's proof
     _prove_both(amd, zkb, f.read_wtns(wt)["w"], 7, 9)
+
+
+def test_single_pass_binning_overflow_falls_back(amd, monkeypatch):
+    """The dense MSMs' single-pass front end gives every (row, bin) a fixed-capacity region; scalars far from uniform
+    overflow it.  With the capacity forced to a few entries (test hook G16_TEST_BIN_CAP) every launch overflows: the
+    flag raised on the device makes msm_collect repeat the launch on the two-pass path -- same proof bytes, and the
+    handle stays on that path for the next proof."""
+    zkb, wt, _ = amd.synth_setup(3000, 5, 2500, 33)
+    w = f.read_wtns(wt)["w"]
+    monkeypatch.setenv("G16_TEST_BIN_CAP", "3")
+    zk = f.read_zkey(zkb)
+    prover = amd.Prover(zkb)
+    monkeypatch.delenv("G16_TEST_BIN_CAP")
+    (A, B, C), opub = g.prove(zk, w, 7, 9)
+    for _ in range(2):
+        proof, pub = prover.prove(f.write_wtns(w), f.le(7), f.le(9))
+        assert proof == f.proof_obj(A, B, C)
+    prover.close()

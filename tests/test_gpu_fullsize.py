@@ -265,3 +265,34 @@ def test_config5_stress_2_22(amd):
         parts.append(sh.prove_partial(0))
         sh.close()
     assert amd.finish_host(zkey, parts, f.le(r), f.le(s)) == proof
+
+
+def test_config4_eight_shards_on_the_live_circuit(amd):
+    """BASELINE config 4 on its own circuit: the nzcp_liveTest constraint system sharded EIGHT ways through the one-process
+    host (g16_multi_*: what Node's createProver(zkey, {devices}) binds) -- all eight shard handles on this GPU, the witness
+    uploaded once and fanned out, slices of the A/B/C coset evaluations moved by asynchronous device copies behind events.
+    A shard of 2^17 H points picks its own window size (the narrow-top-window cliff of r02 sat exactly here).  The proof
+    must equal the unsharded handle's bytes, twice (the second proof reuses every buffer and thread)."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import nzcp_pass
+    tbs = nzcp_pass.to_be_signed("Aroha", "Ngata", "1975-07-21", live=True, exp=1800000000)
+    out = amd.nzcp_circuit_setup(amd.NZCP_LIVE_PARAMS, tbs, 78)
+    r, s = _rs(78)
+    prover = amd.Prover(out["zkey"])
+    proof, pub = prover.prove(out["wtns"], f.le(r), f.le(s))
+    prover.close()
+    assert _verifies(_vk(out["vkey"]), pub, proof)
+    mp = amd.MultiProver(out["zkey"], [0] * 8)
+    assert mp.n_shards == 8
+    for _ in range(2):
+        p8, pub8 = mp.prove(out["wtns"], f.le(r), f.le(s))
+        assert p8 == proof and pub8 == pub
+    # a witness word that is not reduced modulo r is refused (the check runs on shard 0, behind the upload)
+    bad = bytearray(out["wtns"])
+    bad[WTNS_BODY + 32 * 5:WTNS_BODY + 32 * 6] = b"\xff" * 32
+    with pytest.raises(amd.G16Error, match="not reduced"):
+        mp.prove(bytes(bad), f.le(r), f.le(s))
+    p8, _ = mp.prove(out["wtns"], f.le(r), f.le(s))
+    assert p8 == proof
+    mp.close()
