@@ -639,18 +639,18 @@ def main():
         src_hash = kernel_costs.kernel_source_hash()
         workload_id = (f"sha256x{args.sha256_blocks}" if args.sha256_blocks > 0 else
                        f"{args.circuit}:{args.n_vars}:{args.n_constraints}")
-        traffic, traffic_note = None, "no PMC summary (profiles/r02_pmc_traffic.json) for this build and workload"
+        traffic, traffic_note = None, "no PMC summary (profiles/r03_pmc_traffic.json) for this build and workload"
         try:
-            pm = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")))
+            pm = json.load(open(os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")))
             if world != 1:
                 traffic_note = "PMC summary is a 1-GPU profile"
             elif pm.get("kernel_src_sha256") != src_hash:
-                traffic_note = "stale: profiles/r02_pmc_traffic.json was taken on other kernel sources (re-run tools/profile_round.sh)"
+                traffic_note = "stale: profiles/r03_pmc_traffic.json was taken on other kernel sources (re-run tools/profile_round.sh)"
             elif pm.get("workload_id") != workload_id:
-                traffic_note = f"profiles/r02_pmc_traffic.json was taken on workload {pm.get('workload_id')}, not {workload_id}"
+                traffic_note = f"profiles/r03_pmc_traffic.json was taken on workload {pm.get('workload_id')}, not {workload_id}"
             else:
                 traffic = pm["avg_traffic_bytes_per_launch"]
-                traffic_note = ("rocprofv3 FETCH_SIZE + WRITE_SIZE per launch, profiles/r02_pmc_traffic.json "
+                traffic_note = ("rocprofv3 FETCH_SIZE + WRITE_SIZE per launch, profiles/r03_pmc_traffic.json "
                                 "(separate --pmc passes, raw counters: see its 'method')")
         except Exception:
             pass

@@ -199,8 +199,10 @@ static __global__ __launch_bounds__(kBinThreads) void msm_bin_direct_kernel(cons
     for (uint32_t g = lo + threadIdx.x; g < hi; g += kBinThreads) {
       uint32_t sc[8];
       (void)msm_load_scalar(scalars, src, g, K, sc);
-      uint32_t j = threadIdx.x % Ws;
-      for (uint32_t t = 0; t < Ws; t++) {
+      // every lane walks the windows in the same order (the rotation of msm_bin_pass_kernel spreads the LDS atomics of a
+      // MULTI-row group over its rows; here the bins of a window are spread by the digits themselves), so the window's
+      // offset, width and row are wave-uniform scalars
+      for (uint32_t j = 0; j < Ws; j++) {
         const uint32_t wj = msm_win_bits(pl, j);
         const uint32_t e = msm_extract(sc, (int)msm_win_off(pl, j), (int)wj);
         const int32_t d = (j == Ws - 1) ? (int32_t)e : (int32_t)e - (int32_t)(1u << (wj - 1));
@@ -215,7 +217,6 @@ static __global__ __launch_bounds__(kBinThreads) void msm_bin_direct_kernel(cons
           if (pass && !(pos & 0x80000000u))
             tmp[pos] = make_uint2(eidx | (neg << 31), ((bucket & lowmask) << pl.wkb) | (j & ((1u << pl.wkb) - 1u)));
         }
-        j = (j + 1 == Ws) ? 0u : j + 1;
       }
     }
     __syncthreads();
@@ -299,6 +300,7 @@ static constexpr uint32_t kMaxLowBits = 12;
 static __global__ __launch_bounds__(256) void msm_bin_sort_kernel(const uint2* __restrict__ tmp,
                                                            const uint32_t* __restrict__ bin_start, MsmPlan pl,
                                                            const uint32_t* __restrict__ bin_cnt, uint32_t direct_cap,
+                                                           const uint32_t* __restrict__ over,
                                                            uint32_t* __restrict__ cnt, uint32_t* __restrict__ sorted) {
   __builtin_amdgcn_s_setprio(3);   // issue priority over the throughput kernels sharing the SIMD (msm.cuh, kLatencyPrio)
   __shared__ uint32_t c[1u << kMaxLowBits];
@@ -307,8 +309,10 @@ static __global__ __launch_bounds__(256) void msm_bin_sort_kernel(const uint2* _
   const uint32_t out_lo = bin_start[rb];
   uint32_t lo = out_lo, hi = bin_start[rb + 1];
   if (direct_cap) {
+    // an overflowed launch is repeated on the two-pass path (msm_collect); until then its bins hold runs with holes -- every
+    // bin counts as empty, so that no kernel downstream reads an entry nobody wrote
     lo = rb * direct_cap;
-    hi = lo + (bin_cnt[rb] < direct_cap ? bin_cnt[rb] : direct_cap);
+    hi = over[0] ? lo : lo + (bin_cnt[rb] < direct_cap ? bin_cnt[rb] : direct_cap);
   }
   const uint32_t nb = 1u << pl.low_bits;          // buckets of the bin
   const uint32_t nl = nb << pl.wkb;               // sort keys
@@ -992,7 +996,9 @@ int msm_workspace_create(MsmWorkspace** out, const MsmGroup& g) {
   }
   G16_HIP(hipHostMalloc((void**)&ws->h_over, 64));
   ws->h_over[0] = 0;
-  const uint64_t tmp_entries = ws->direct ? (uint64_t)ws->bin_cap * nrb : g.max_entries;
+  // (the two-pass path -- the fallback of an overflowing single-pass launch -- needs room for every entry whatever the capacity)
+  uint64_t tmp_entries = g.max_entries;
+  if (ws->direct && (uint64_t)ws->bin_cap * nrb > tmp_entries) tmp_entries = (uint64_t)ws->bin_cap * nrb;
   G16_HIP(hipMalloc(&ws->d_tmp, (tmp_entries + 4) * sizeof(uint2)));
   G16_HIP(hipMalloc(&ws->d_sorted, (g.max_entries + 4) * 4));
   G16_HIP(hipMalloc(&ws->d_cnt, ((size_t)ws->nb + 4) * 4));
@@ -1057,7 +1063,8 @@ int msm_front_end(const MsmGroup& g, MsmWorkspace* ws, const Fr* d_scalars, hipS
     mark(1);
     msm_bin_scan_kernel<<<1, 1024, 0, st>>>(ws->d_bin_cnt, nrb, ws->d_bin_start, ws->bin_cap);
     mark(2);
-    msm_bin_sort_kernel<<<nrb, 256, 0, st>>>(ws->d_tmp, ws->d_bin_start, pl, ws->d_bin_cnt, ws->bin_cap, ws->d_cnt, ws->d_sorted);
+    msm_bin_sort_kernel<<<nrb, 256, 0, st>>>(ws->d_tmp, ws->d_bin_start, pl, ws->d_bin_cnt, ws->bin_cap, ws->h_over, ws->d_cnt,
+                                             ws->d_sorted);
     mark(3);
   } else {
     msm_bin_pass_kernel<0><<<g.chunks, kBinThreads, lds, st>>>(d_scalars, g.d_src, pl, K, g.per, g.chunks, ws->d_hist, nullptr,
@@ -1069,7 +1076,7 @@ int msm_front_end(const MsmGroup& g, MsmWorkspace* ws, const Fr* d_scalars, hipS
     msm_bin_pass_kernel<1><<<g.chunks, kBinThreads, lds, st>>>(d_scalars, g.d_src, pl, K, g.per, g.chunks, ws->d_hist,
                                                                ws->d_bin_start, ws->d_dup_cnt, ws->d_dup_mixed, ws->d_tmp);
     mark(2);
-    msm_bin_sort_kernel<<<nrb, 256, 0, st>>>(ws->d_tmp, ws->d_bin_start, pl, nullptr, 0u, ws->d_cnt, ws->d_sorted);
+    msm_bin_sort_kernel<<<nrb, 256, 0, st>>>(ws->d_tmp, ws->d_bin_start, pl, nullptr, 0u, nullptr, ws->d_cnt, ws->d_sorted);
     mark(3);
   }
   G16_HIP(hipGetLastError());

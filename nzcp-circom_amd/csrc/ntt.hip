@@ -37,6 +37,16 @@ static int env_int(const char* name, int dflt) {
 
 struct VecPtrs { F29* p[4]; };
 
+// Issue priority of the NTT wavefronts (s_setprio), G16_CHAIN_PRIO = 0..3 at create: the QAP -> NTT chain is the head of a
+// proof's critical path and shares the chip with the witness group's bucket accumulation (prio 0, a persistent grid).
+__device__ int g_ntt_prio = 0;
+__device__ __forceinline__ void ntt_set_prio() {
+  const int p = g_ntt_prio;
+  if (p == 1) __builtin_amdgcn_s_setprio(1);
+  else if (p == 2) __builtin_amdgcn_s_setprio(2);
+  else if (p >= 3) __builtin_amdgcn_s_setprio(3);
+}
+
 __device__ __forceinline__ uint32_t bitrev_dev(uint32_t x, int bits) {
   return bits == 0 ? 0u : (__brev(x) >> (32 - bits));
 }
@@ -91,6 +101,7 @@ __device__ __forceinline__ void ntt_tile_stages(F29* __restrict__ tile, const F2
 __global__ __launch_bounds__(kThreads) void ntt_pass_kernel(VecPtrs vecs, const F29* __restrict__ tw,
                                                             int L, int tile_log, int lo_bits, int S,
                                                             int tb, int dif, const F29* __restrict__ post) {
+  ntt_set_prio();
   extern __shared__ __align__(16) unsigned char ntt_lds[];
   F29* tile = reinterpret_cast<F29*>(ntt_lds);
   F29* __restrict__ x = vecs.p[blockIdx.y];
@@ -128,6 +139,7 @@ __global__ __launch_bounds__(kThreads) void ntt_pass_kernel(VecPtrs vecs, const 
 __global__ __launch_bounds__(kThreads) void ntt_mid_pass_kernel(VecPtrs vecs, const F29* __restrict__ tw_inv,
                                                                 const F29* __restrict__ tw_fwd, int L, int tile_log,
                                                                 const F29* __restrict__ post) {
+  ntt_set_prio();
   extern __shared__ __align__(16) unsigned char ntt_lds[];
   F29* tile = reinterpret_cast<F29*>(ntt_lds);
   F29* __restrict__ x = vecs.p[blockIdx.y];
@@ -152,6 +164,7 @@ template <int EPT>   // tile elements per thread = max(1, tile_n / 256)
 __global__ __launch_bounds__(kThreads) void ntt_last_pass_join_kernel(VecPtrs vecs, const F29* __restrict__ tw, int L,
                                                                       int tile_log, int lo_bits, int S, int tb,
                                                                       Fr* __restrict__ p_out) {
+  ntt_set_prio();
   extern __shared__ __align__(16) unsigned char ntt_lds[];
   F29* tile = reinterpret_cast<F29*>(ntt_lds);
   const uint32_t tile_n = 1u << tile_log;
@@ -241,6 +254,10 @@ static Fr host_from_u64(uint64_t v) {
 int ntt_tables_create(NttTables& t, int L, hipStream_t st) {
   if (L < 0 || L > 27) { set_error("domainSize out of range (need 2^0..2^27)"); return G16_E_ARG; }
   t.L = L;
+  {
+    const int prio = env_int("G16_CHAIN_PRIO", 0);
+    G16_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_ntt_prio), &prio, sizeof(int)));
+  }
   // r01 sweep on MI355X (N = 2^21, three vectors): tile 2^9 = 1.64 ms, 2^10 = 1.84, 2^11 = 2.1, 2^8 = 2.1:
   // a 20 KiB tile keeps 8 workgroups resident per CU, which matters more than saving a pass.
   int tile_max = env_int("G16_NTT_TILE_LOG", 9);

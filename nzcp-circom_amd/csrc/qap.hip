@@ -9,15 +9,27 @@
 // the witness word is in standard form, so ONE Montgomery product gives Montgomery(coef*w).  Here the
 // coefficients are converted once to the kernels' 9x29 lazy format with the radix-2^261 equivalent
 // (coef * 2^522), and the sums are lazy (fr29.cuh).
+#include <stdlib.h>
+
 #include "fr29.cuh"
 #include "internal.h"
 
 namespace g16 {
 
+// issue priority of the QAP wavefronts: see ntt.hip g_ntt_prio (G16_CHAIN_PRIO)
+__device__ int g_qap_prio = 0;
+__device__ __forceinline__ void qap_set_prio() {
+  const int p = g_qap_prio;
+  if (p == 1) __builtin_amdgcn_s_setprio(1);
+  else if (p == 2) __builtin_amdgcn_s_setprio(2);
+  else if (p >= 3) __builtin_amdgcn_s_setprio(3);
+}
+
 __global__ __launch_bounds__(256) void qap_eval_kernel(
     const uint32_t* __restrict__ rpA, const uint32_t* __restrict__ colA, const F29* __restrict__ valA,
     const uint32_t* __restrict__ rpB, const uint32_t* __restrict__ colB, const F29* __restrict__ valB,
     const Fr* __restrict__ w, F29* __restrict__ a, F29* __restrict__ b, F29* __restrict__ cc, uint32_t N) {
+  qap_set_prio();
   const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= N) return;
   if (rpA[c + 1] - rpA[c] > kQapLongRow || rpB[c + 1] - rpB[c] > kQapLongRow) return;   // qap_long_rows_kernel's
@@ -52,6 +64,7 @@ __global__ __launch_bounds__(64) void qap_long_rows_kernel(
     const uint32_t* __restrict__ rpA, const uint32_t* __restrict__ colA, const F29* __restrict__ valA,
     const uint32_t* __restrict__ rpB, const uint32_t* __restrict__ colB, const F29* __restrict__ valB,
     const Fr* __restrict__ w, F29* __restrict__ a, F29* __restrict__ b, F29* __restrict__ cc) {
+  qap_set_prio();
   if (blockIdx.x >= n_long) return;
   const uint32_t c = rows[blockIdx.x], lane = threadIdx.x;
   F29 s[2] = {f29_zero(), f29_zero()};
@@ -118,6 +131,10 @@ int qap_check_witness(const Fr* w_std, uint32_t n, uint32_t* d_flag, uint32_t* h
 
 int qap_convert_coefs(const Fr* in, F29* out, size_t n, hipStream_t st) {
   if (n == 0) return G16_OK;
+  {
+    const int prio = getenv("G16_CHAIN_PRIO") ? atoi(getenv("G16_CHAIN_PRIO")) : 0;
+    G16_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_qap_prio), &prio, sizeof(int)));
+  }
   qap_convert_kernel<<<(unsigned)((n + 255) / 256), 256, 0, st>>>(in, out, n);
   G16_HIP(hipGetLastError());
   return G16_OK;
