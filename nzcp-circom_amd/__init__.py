@@ -15,7 +15,7 @@ import json
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libg16hip.so")
+LIB_PATH = os.path.join(_HERE, "lib", os.environ.get("G16_LIB_NAME", "libg16hip.so"))   # (G16_LIB_NAME: A/B of two builds)
 PARTIAL_BYTES = 128 * 4 + 256
 LAZY_FR_BYTES = 40
 

@@ -99,10 +99,11 @@ struct QapCsr {
   uint32_t N = 0;
   // rows with more than kQapLongRow terms in A or B (the modular-addition rows of a SHA-256 circuit carry
   // ~260): one wavefront each instead of one lane
-  uint32_t* long_rows = nullptr;
-  uint32_t n_long = 0;
+  uint32_t* long_rows = nullptr;   // first the n_mid rows of at most kQapWaveRow terms (eight lanes each), then the rest
+  uint32_t n_long = 0, n_mid = 0;
 };
 static constexpr uint32_t kQapLongRow = 16;
+static constexpr uint32_t kQapWaveRow = 64;
 // a[c] = sum val*w[col] (lazy Montgomery), b likewise, cc = a*b; w is the standard-form witness
 int qap_eval(const QapCsr& q, const Fr* w_std, F29* a, F29* b, F29* cc, hipStream_t st);
 // canonicity of the staged witness words: *h_flag (pinned) <- lowest index of a word >= r, or 0xffffffff, once `st`
@@ -201,7 +202,7 @@ struct MsmResult {
 };
 static constexpr uint32_t kDupMin = 8;       // points sharing a value before the dup row pays (1 entry + ~127 tree
                                              // additions per value against one entry per window)
-static constexpr uint32_t kDupChunkBits = 16; // a repeated value is cut into chunks of this many bits ...
+static constexpr uint32_t kDupChunkBits = 16; // a repeated value is cut into chunks of this many bits (8: measured in r03, profiles/r03_sweeps.txt) ...
 static constexpr uint32_t kDupBitRows = (254 + kDupChunkBits - 1) / kDupChunkBits;   // ... one output row per chunk
 // msm_launch only enqueues: front end + G1 lane on `st`, the G2 lane (if any) forks onto `st2` after the sort
 // (st2 == nullptr or == st: same stream).  msm_collect waits for both, folds the window sums on the host

@@ -17,14 +17,21 @@ __device__ __forceinline__ uint32_t msm_extract(const uint32_t s[8], int pos, in
   return (uint32_t)(v >> off) & ((1u << c) - 1);
 }
 
-// Loads the scalar of point g, adds K; returns true when the scalar is exactly 1.
+// Loads the scalar of point g, adds K; returns true when the scalar is exactly 1.  *bits (optional) <- bit length of the scalar.
 __device__ __forceinline__ bool msm_load_scalar(const Fr* __restrict__ scalars, const uint32_t* __restrict__ src,
-                                                uint32_t g, const U256& K, uint32_t s[8]) {
+                                                uint32_t g, const U256& K, uint32_t s[8], uint32_t* bits = nullptr) {
   const Fr x = scalars[src[g]];
   uint32_t hi = 0;
 #pragma unroll
   for (int k = 1; k < 8; k++) hi |= x.v[k];
   const bool one = (hi == 0 && x.v[0] == 1);
+  if (bits) {
+    uint32_t b = 0;
+#pragma unroll
+    for (int k = 0; k < 8; k++)
+      if (x.v[k]) b = 32u * (uint32_t)k + 32u - (uint32_t)__clz(x.v[k]);
+    *bits = b;
+  }
   uint64_t cy = 0;
 #pragma unroll
   for (int k = 0; k < 8; k++) {
@@ -108,7 +115,7 @@ static __global__ __launch_bounds__(kBinThreads) void msm_bin_pass_kernel(const 
   for (uint32_t g0 = lo; g0 < hi; g0 += kBinThreads) {   // uniform trip count: the ballots below need every lane
     const uint32_t g = g0 + threadIdx.x;
     const bool live = g < hi;
-    uint32_t s = 0, i = 0, row0 = 0;
+    uint32_t s = 0, i = 0, row0 = 0, bits = 0;
     uint32_t sc[8];
     bool one = false;
     if (live) {
@@ -116,7 +123,7 @@ static __global__ __launch_bounds__(kBinThreads) void msm_bin_pass_kernel(const 
       if (pl.nsec > 2 && g >= pl.sec_begin[2]) s = 2;
       i = g - pl.sec_begin[s];
       row0 = s * pl.rps;
-      one = msm_load_scalar(scalars, src, g, K, sc);
+      one = msm_load_scalar(scalars, src, g, K, sc, &bits);
     }
     if (pl.ones) {
       // wave-aggregated count of the ones: lanes with the same (row, bin) share one atomic
@@ -151,8 +158,14 @@ static __global__ __launch_bounds__(kBinThreads) void msm_bin_pass_kernel(const 
         }
       }
     }
-    uint32_t j = threadIdx.x % Ws;
-    for (uint32_t t = 0; t < Ws; t++) {
+    // Only the windows the scalar reaches: above its top bit, x + K holds the bits of K alone -- digit 0 -- except for ONE
+    // carry into the next window.  A witness is mostly zeros and small values (63 % / ~20 % of the NZCP witness): r02 walked
+    // all Ws = 20 windows of every point, 1 250 instructions per point and pass -- as many VALU instructions in the two bin
+    // passes as in both witness bucket accumulations together (profiles/r03_sweeps.txt).
+    uint32_t nwin = bits ? (bits - 1u) / pl.wb + 2u : 0u;
+    if (nwin > Ws) nwin = Ws;
+    uint32_t j = nwin ? threadIdx.x % nwin : 0u;
+    for (uint32_t t = 0; t < nwin; t++) {
       const uint32_t wj = msm_win_bits(pl, j);
       const uint32_t e = msm_extract(sc, (int)msm_win_off(pl, j), (int)wj);
       const int32_t d = (j == Ws - 1) ? (int32_t)e : (int32_t)e - (int32_t)(1u << (wj - 1));   // the top window stays unsigned
@@ -166,7 +179,7 @@ static __global__ __launch_bounds__(kBinThreads) void msm_bin_pass_kernel(const 
         const uint32_t pos = atomicAdd(&lds[rb], 1u);
         if (MODE) tmp[pos] = make_uint2(eidx | (neg << 31), ((bucket & lowmask) << pl.wkb) | (j & ((1u << pl.wkb) - 1u)));
       }
-      j = (j + 1 == Ws) ? 0u : j + 1;
+      j = (j + 1 == nwin) ? 0u : j + 1;
     }
   }
   if (!MODE) {
@@ -590,6 +603,17 @@ static void msm_make_K(const MsmPlan& pl, U256& K) {
   }
 }
 
+// Entries per accumulate task from the entries one lane of the persistent grid gets: one task per lane, within [lo, 32]
+// (short tasks keep the drain tail of the persistent kernel small: r01 sweep) -- but once a lane gets more than four
+// 32-entry tasks, a quarter of its share, up to 128: at N = 2^22 a bucket holds 100-150 entries, 32-entry tasks cut every
+// bucket into 4-5 partial sums and the combine pass took as long as the accumulation itself (r03, SHA-256 chain of 163
+// compressions, serial stages: accumulate 4.09 ms, combine 3.74 ms).
+static uint32_t msm_task_len_for(uint64_t per_lane, uint32_t lo) {
+  uint64_t t = per_lane < lo ? lo : (per_lane > 32 ? 32 : per_lane);
+  if (per_lane / 4 > 32) t = per_lane / 4 > 128 ? 128 : per_lane / 4;
+  return (uint32_t)t;
+}
+
 static MsmPlan msm_plan_of(const MsmGroup& g) {
   MsmPlan pl{};
   pl.nsec = (uint32_t)g.nsec;
@@ -819,8 +843,7 @@ int msm_group_create(MsmGroup& g, const MsmSectionIn* secs, int nsec, const MsmC
   } else {
     uint64_t entries = 0;
     for (int s = 0; s < nsec; s++) entries += (uint64_t)(cfg.dense ? g.sec_n[s] : g.sec_n[s] / 3 + 1) * g.Ws;
-    const uint64_t t = entries / 262144;
-    g.task_len = (uint32_t)(t < 16 ? 16 : (t > 32 ? 32 : t));
+    g.task_len = msm_task_len_for(entries / 262144, 16);
   }
   g.task_len_forced = cfg.task_len != 0;
   g.max_entries = (uint64_t)g.n * (uint32_t)g.Ws;
@@ -875,8 +898,7 @@ static int lane_create(MsmLaneWs& ln, const MsmGroup& g, int curve, uint32_t key
   // task length: fill the lane's persistent grid (G1: 4 wavefronts per SIMD = 262144 lanes, G2: 2 = 131072)
   ln.task_len = g.task_len;
   if (curve == 2 && !g.task_len_forced) {
-    const uint64_t t = entries_eff / 131072;
-    ln.task_len = (uint32_t)(t < 16 ? 16 : (t > 32 ? 32 : t));
+    ln.task_len = msm_task_len_for(entries_eff / 131072, 16);
   }
   ln.seg_len = msm_seg_len_cfg(curve == 2 ? 1 : (g.dense ? 2 : 0));
   while (ln.seg_len & (ln.seg_len - 1)) ln.seg_len &= ln.seg_len - 1;   // a power of two (msm_bucket_reduce_kernel)
@@ -1094,8 +1116,7 @@ int msm_build_queue(const MsmGroup& g, MsmWorkspace* ws, MsmLaneWs& ln, hipStrea
   const uint32_t ntiles = (nbk + kScanTile - 1) / kScanTile;
   if (!g.task_len_forced && ln.h_stat[0] > ln.h_stat[1]) {   // entries of the previous launch (its copies completed
     const uint64_t e = ln.h_stat[0] - ln.h_stat[1];          // before msm_collect returned): one task per lane of the
-    const uint64_t t = e / (ln.curve == 2 ? 131072u : 262144u);   // persistent grid, within [min, 32]
-    ln.task_len = (uint32_t)(t < ln.task_len_min ? ln.task_len_min : (t > 32 ? 32 : t));
+    ln.task_len = msm_task_len_for(e / (ln.curve == 2 ? 131072u : 262144u), ln.task_len_min);   // persistent grid
   }
   msm_scan_tiles_kernel<<<ntiles, 256, 0, st>>>(cnt, nbk, ln.task_len, ln.d_tile_a, ln.d_tile_b, ln.d_tile_c);
   msm_scan_top_kernel<<<1, 1024, 0, st>>>(ln.d_tile_a, ln.d_tile_b, ln.d_tile_c, ntiles, off_base, ln.d_off + nbk,

@@ -225,9 +225,14 @@ static int build_csr(g16_prover* P, const Section& s4) {
   }
   P->csr.N = N;
   {
-    std::vector<uint32_t> long_rows;
-    for (uint32_t c = 0; c < N; c++)
-      if (rp[0][c + 1] - rp[0][c] > kQapLongRow || rp[1][c + 1] - rp[1][c] > kQapLongRow) long_rows.push_back(c);
+    std::vector<uint32_t> long_rows, wave_rows;
+    for (uint32_t c = 0; c < N; c++) {
+      const uint32_t la = rp[0][c + 1] - rp[0][c], lb = rp[1][c + 1] - rp[1][c], mx = la > lb ? la : lb;
+      if (mx > kQapWaveRow) wave_rows.push_back(c);
+      else if (mx > kQapLongRow) long_rows.push_back(c);
+    }
+    P->csr.n_mid = (uint32_t)long_rows.size();
+    long_rows.insert(long_rows.end(), wave_rows.begin(), wave_rows.end());
     P->csr.n_long = (uint32_t)long_rows.size();
     if (!long_rows.empty()) {
       G16_HIP(hipMalloc(&P->csr.long_rows, long_rows.size() * 4));

@@ -59,14 +59,21 @@ __device__ __forceinline__ F29 f29_shfl_xor(const F29& v, int mask) {
   r.pad_ = 0;
   return r;
 }
-__global__ __launch_bounds__(64) void qap_long_rows_kernel(
+// GW lanes per long row (GW = 64: a wavefront; GW = 8: eight rows per wavefront): lanes stride over the row's records,
+// partial sums meet in a log2(GW)-step __shfl_xor tree (weak-reduced on the way so they stay below 16r).
+// The real NZCP circuit has 48 k rows of 17-32 terms (and a single B term) beside its 2.5 k rows of 65-356 terms: with a
+// whole wavefront per row (r02) those 48 k rows cost 65 M wavefront-instructions -- 4 % of a proof, two 6-step trees over
+// mostly empty lanes each; eight-lane groups do them for a tenth of that.
+template <int GW>
+__global__ __launch_bounds__(256) void qap_long_rows_kernel(
     const uint32_t* __restrict__ rows, uint32_t n_long,
     const uint32_t* __restrict__ rpA, const uint32_t* __restrict__ colA, const F29* __restrict__ valA,
     const uint32_t* __restrict__ rpB, const uint32_t* __restrict__ colB, const F29* __restrict__ valB,
     const Fr* __restrict__ w, F29* __restrict__ a, F29* __restrict__ b, F29* __restrict__ cc) {
   qap_set_prio();
-  if (blockIdx.x >= n_long) return;
-  const uint32_t c = rows[blockIdx.x], lane = threadIdx.x;
+  const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x, gid = tid / GW, lane = tid % GW;
+  if (gid >= n_long) return;   // (whole groups leave together: the shuffles below stay inside a group)
+  const uint32_t c = rows[gid];
   F29 s[2] = {f29_zero(), f29_zero()};
 #pragma unroll
   for (int m = 0; m < 2; m++) {
@@ -74,12 +81,12 @@ __global__ __launch_bounds__(64) void qap_long_rows_kernel(
     const uint32_t* col = m ? colB : colA;
     const F29* val = m ? valB : valA;
     uint32_t cnt = 0;
-    for (uint32_t k = rp[c] + lane, e = rp[c + 1]; k < e; k += 64) {
+    for (uint32_t k = rp[c] + lane, e = rp[c + 1]; k < e; k += GW) {
       s[m] = fr29_add(s[m], fr29_mul(val[k], fr29_repack(w[col[k]])));
       if ((++cnt & 7u) == 0) s[m] = fr29_weak_reduce(s[m]);
     }
     s[m] = fr29_weak_reduce(s[m]);
-    for (int d = 32; d >= 1; d >>= 1) {
+    for (int d = GW / 2; d >= 1; d >>= 1) {
       s[m] = fr29_add(s[m], f29_shfl_xor(s[m], d));
       if (d == 8 || d == 1) s[m] = fr29_weak_reduce(s[m]);   // at most 8 partials below ~2r between reductions
     }
@@ -99,9 +106,14 @@ __global__ __launch_bounds__(256) void qap_convert_kernel(const Fr* __restrict__
 int qap_eval(const QapCsr& q, const Fr* w_std, F29* a, F29* b, F29* cc, hipStream_t st) {
   qap_eval_kernel<<<(q.N + 255) / 256, 256, 0, st>>>(q.row_ptr[0], q.col[0], q.val[0], q.row_ptr[1],
                                                       q.col[1], q.val[1], w_std, a, b, cc, q.N);
-  if (q.n_long)
-    qap_long_rows_kernel<<<q.n_long, 64, 0, st>>>(q.long_rows, q.n_long, q.row_ptr[0], q.col[0], q.val[0], q.row_ptr[1],
-                                                  q.col[1], q.val[1], w_std, a, b, cc);
+  // long_rows = [the n_mid rows of kQapLongRow < terms <= kQapWaveRow][the rows above]
+  if (q.n_mid)
+    qap_long_rows_kernel<8><<<(q.n_mid + 31) / 32, 256, 0, st>>>(q.long_rows, q.n_mid, q.row_ptr[0], q.col[0], q.val[0],
+                                                                q.row_ptr[1], q.col[1], q.val[1], w_std, a, b, cc);
+  if (q.n_long > q.n_mid)
+    qap_long_rows_kernel<64><<<(q.n_long - q.n_mid + 3) / 4, 256, 0, st>>>(q.long_rows + q.n_mid, q.n_long - q.n_mid, q.row_ptr[0],
+                                                                          q.col[0], q.val[0], q.row_ptr[1], q.col[1], q.val[1],
+                                                                          w_std, a, b, cc);
   G16_HIP(hipGetLastError());
   return G16_OK;
 }
