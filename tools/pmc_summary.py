@@ -79,15 +79,23 @@ with open(os.path.join(prof, f"{tag}_pmc_accumulate.txt"), "w") as o:
             "--batch-streams 0; rows = dispatches of the last proof (tools/profile_round.sh)\n")
     o.write("# pass 3: SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU "
             "SQ_INSTS_VALU SQ_WAVES\n")
+    # SQ_WAVE_CYCLES per wave, in units calibrated on the persistent H accumulate grid (its waves live as long as the
+    # kernel): wave_life = average wave lifetime / kernel duration.  A tail kernel with wave_life well below 1 lasts as long
+    # as its LONGEST dependency chain, so valu_insts_per_wave (an average) and simd_cycles_per_valu_inst understate what its
+    # slowest waves do (r03: profiles/r03_sweeps.txt section 2).
+    hacc = [r for r in p3 if "msm_accumulate_kernel<g16::Fq29Ops>" in r["name"]]
+    unit = max((r.get("SQ_WAVE_CYCLES", 0) / max(r.get("SQ_WAVES", 1), 1) / r["dur_ms"] for r in hacc), default=0.0)
+    o.write("# wave_life = (SQ_WAVE_CYCLES / SQ_WAVES) / kernel duration, normalised to the persistent H accumulate grid (= 1.00)\n")
     for r in p3:
         if not r["name"].startswith(("void g16::msm_", "g16::ntt", "g16::qap", "g16::msm_", "void g16::")):
             continue
         w, wc = max(r.get("SQ_WAVES", 1), 1), max(r.get("SQ_WAVE_CYCLES", 1), 1)
         iv = r.get("SQ_INSTS_VALU", 0)
+        life = (wc / w / r["dur_ms"] / unit) if unit and r["dur_ms"] else 0.0
         o.write(f"{short(r['name']):44s} grid={r['grid']:8d} dur_ms={r['dur_ms']:.3f} waves={int(w)} "
                 f"valu_insts_per_wave={iv / w:.0f} simd_cycles_per_valu_inst={r['dur_ms'] * 1e-3 * 2.4e9 / max(iv / 1024, 1):.2f} "
                 f"wait_mem/wave_cyc={r.get('SQ_WAIT_ANY', 0) / wc:.2f} issue_stall/wave_cyc={r.get('SQ_WAIT_INST_ANY', 0) / wc:.2f} "
-                f"active/wave_cyc={r.get('SQ_ACTIVE_INST_ANY', 0) / wc:.2f}\n")
+                f"active/wave_cyc={r.get('SQ_ACTIVE_INST_ANY', 0) / wc:.2f} wave_life={life:.2f}\n")
     o.write("# pass 1: FETCH_SIZE (KiB, raw)   pass 2: WRITE_SIZE (KiB), TCC_HIT_sum, TCC_MISS_sum\n")
     for a, b in zip(p1, p2):
         if any(k in a["name"] for k in ("accumulate", "ntt_pass", "ntt_last", "bin_pass", "bin_sort", "qap_eval")):
