@@ -717,8 +717,8 @@ def main():
                 "ntt_x6_join": {"algorithmic_bytes": 320 * N,
                                 "GBps": round(320 * N / (acc["ntt_ms"] / K * 1e-3) / 1e9, 1) if acc["ntt_ms"] else None,
                                 "frac": round(320 * N / (acc["ntt_ms"] / K * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if acc["ntt_ms"] else None,
-                                "note": "VALU-bound like the MSM: ~340 instructions per butterfly, 5.3-6.1 cycles each "
-                                        "(profiles/r02_pmc_accumulate.txt)"}},
+                                "note": "VALU-bound like the MSM: 317 VALU instructions per butterfly (floor 289), 5.2-6.2 cycles each "
+                                        "(profiles/r03_pmc_accumulate.txt)"}},
             "proof_hbm_GBps": round(b_proof / (acc["total_ms"] / K * 1e-3) / 1e9, 2) if acc["total_ms"] else None,
             "roofline": {"bound": "hbm", "kernel": "msm_accumulate_kernel<G1> (avg over its two launches per proof: fused witness group A+B1+C, and H)",
                          "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",

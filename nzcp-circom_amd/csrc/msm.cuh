@@ -13,25 +13,31 @@
 //   as a second accumulate "lane"; the H-MSM is a group of its own.
 //
 //   front end (msm_g1.hip, curve independent)
-//   1. msm_bin_pass_kernel<0/1>: signed c-bit digits straight from the scalars (carry-free: one 256-bit add of
-//      the constant K = sum 2^(c-1) 2^(cj) turns signed recoding into plain bit extraction), counted
-//      (pass 0) and then scattered (pass 1) into (row, bin) runs, bin = the high bits of the bucket: every
-//      workgroup writes contiguous runs.  The scalar value 1 (~30 % of an NZCP witness) goes to
-//      an extra UNWEIGHTED row per section, spread over its buckets, so there is no giant bucket.
+//   1. witness groups -- msm_bin_pass_kernel<0/1>: signed c-bit digits straight from the scalars (carry-free: one
+//      256-bit add of the constant K = sum 2^(c-1) 2^(cj) turns signed recoding into plain bit extraction; only the
+//      windows a scalar reaches are walked), counted (pass 0) and then scattered (pass 1) into (row, bin) runs, bin =
+//      the high bits of the bucket: every workgroup writes contiguous runs.  The scalar value 1 (~30 % of an NZCP
+//      witness) goes to an extra UNWEIGHTED row per section, spread over its buckets; repeated values
+//      to the dup rows (internal.h MsmGroup::dup_rows).
+//      dense groups (H, PLONK commitments) -- msm_bin_direct_kernel: ONE pass into fixed-capacity bins (count in LDS,
+//      claim a run per bin with one global atomic, scatter); windows of EVEN width (MsmGroup::wb); an overflowing bin
+//      makes the launch inert and msm_collect repeats it on the two-pass path.
 //   2. msm_bin_sort_kernel: one workgroup per (row, bin) counts the low bucket bits in LDS, writes the bucket
 //      populations and the final sorted list of its own contiguous output range.  No global atomics, and the
 //      HBM writes of the sort are the payload, not one sector per 4-byte entry.
-//   3. msm_scan_*: exclusive scans of the bucket populations -> entry offsets, task ids, queue positions.
+//   3. msm_scan_*: exclusive scans of the bucket populations -> entry offsets, task ids, queue positions; the task
+//      total is checked against the capacity of the task buffers there (over capacity: G16_E_STATE, not a fault).
 //   per lane (this header, instantiated for G1 in msm_g1.hip and for G2 in msm_g2.hip)
-//   4. msm_rem_count / msm_task_fill (msm_g1.hip): buckets are cut into tasks of <= task_len sorted entries,
+//   4. msm_task_fill (msm_g1.hip): buckets are cut into tasks of <= task_len sorted entries,
 //      queued full-length tasks first, remainders by length class.
 //   5. msm_accumulate_kernel: persistent wavefronts over the task queue; a lane walks its task's slice of
 //      the sorted list, gathers the packed 64/128-byte affine point and mixed-adds it into an XYZZ
 //      accumulator held in VGPRs; a finished lane takes the next task.
-//   6. msm_combine_light/heavy_kernel: buckets cut into several tasks -> one sum per bucket.
-//   7. msm_bucket_reduce_kernel: per row, sum k*S_k by running sums over segments of buckets plus a short
-//      double-and-add for the segment offset; msm_wave_reduce_kernel: 64 -> 1 tree per wavefront with
-//      __shfl_down of the limbs; msm_to_canon_kernel: back to the canonical image.
+//   6. msm_combine_light/medium/heavy_kernel: buckets cut into several tasks -> one sum per bucket.
+//   7. row sums sum_b (b + 1) S_b.  Dense rows: msm_bucket_reduce_kernel (running sums per segment, the segments' weights
+//      by suffix SCANS over the lanes -- no per-lane multiplication) + msm_pairs_fold_kernel + a host fold of 16 triples;
+//      sparse rows (witness lanes): msm_bucket_reduce_mul_kernel (r02: a short double-and-add per segment, free for an
+//      empty segment) + msm_row_final_kernel.  Dup rows: msm_dup_bits_kernel + msm_wave_reduce_kernel trees.
 //   Row sums go back to the host, which does the c doublings per row (internal.h msm_combine_windows).
 //
 // Roofline note: ~2.2k VALU instructions (1.47k v_mad_u64_u32) per

@@ -396,6 +396,11 @@ static __global__ __launch_bounds__(256) void msm_bin_sort_kernel(const uint2* _
 // scan + tile offset.
 static constexpr uint32_t kScanTile = 2048;   // 256 threads x 8 counters
 
+// relative-length class of a remainder task (see the task queues below)
+__device__ __forceinline__ uint32_t msm_rem_class(uint32_t len, uint32_t task_len) {
+  return (len * kRemClasses) / task_len;      // len < task_len -> 0 .. kRemClasses - 1
+}
+
 static __global__ __launch_bounds__(256) void msm_scan_tiles_kernel(const uint32_t* __restrict__ cnt, uint32_t nb,
                                                              uint32_t tl, uint32_t* __restrict__ tile_a,
                                                              uint32_t* __restrict__ tile_b,
@@ -483,9 +488,14 @@ static __global__ __launch_bounds__(256) void msm_scan_apply_kernel(const uint32
                                                              const uint32_t* __restrict__ queue,
                                                              uint32_t* __restrict__ off,
                                                              uint32_t* __restrict__ toff,
-                                                             uint32_t* __restrict__ foff) {
+                                                             uint32_t* __restrict__ foff,
+                                                             uint32_t* __restrict__ class_total) {
   __builtin_amdgcn_s_setprio(3);   // issue priority over the throughput kernels sharing the SIMD (msm.cuh, kLatencyPrio)
   __shared__ uint32_t sh_a[256], sh_b[256], sh_c[256];
+  // class_total[c] += remainder tasks (cnt % task_len != 0) of relative-length class c among this tile's buckets (zeroed by
+  // msm_scan_top_kernel, which runs before; r02 had a kernel of its own for this: one dependent launch less per lane)
+  __shared__ uint32_t sh_cls[kRemClasses];
+  if (threadIdx.x < kRemClasses) sh_cls[threadIdx.x] = 0;
   const uint32_t tid = threadIdx.x, base = blockIdx.x * kScanTile + tid * 8;
   uint32_t v[8], sa = 0, sb = 0, sc = 0;
 #pragma unroll
@@ -497,6 +507,11 @@ static __global__ __launch_bounds__(256) void msm_scan_apply_kernel(const uint32
   }
   sh_a[tid] = sa; sh_b[tid] = sb; sh_c[tid] = sc;
   __syncthreads();
+#pragma unroll
+  for (int k = 0; k < 8; k++) {
+    const uint32_t r = v[k] % tl;
+    if (r) atomicAdd(&sh_cls[msm_rem_class(r, tl)], 1u);
+  }
   for (uint32_t d = 1; d < 256; d <<= 1) {
     uint32_t va = 0, vb = 0, vc = 0;
     if (tid >= d) { va = sh_a[tid - d]; vb = sh_b[tid - d]; vc = sh_c[tid - d]; }
@@ -518,6 +533,8 @@ static __global__ __launch_bounds__(256) void msm_scan_apply_kernel(const uint32
     pb += (v[k] + tl - 1) / tl;
     pc += v[k] / tl;
   }
+  // (the scan loop above ends with a barrier: every lane's class counts are in)
+  if (tid < kRemClasses && sh_cls[tid] && !over) atomicAdd(&class_total[tid], sh_cls[tid]);
 }
 
 // ---------------------------------------------------------------------- task queues (per lane)
@@ -528,25 +545,6 @@ static __global__ __launch_bounds__(256) void msm_scan_apply_kernel(const uint32
 // of the accumulate loop runs once per task instead of in nearly every iteration, and the queue ends with its
 // shortest tasks (a shorter drain).  qdesc[q] = (first entry, count, task id, -).  Task ids and queue positions
 // are local to the lane (its key range [key_lo, key_hi) of the group, its own task length).
-__device__ __forceinline__ uint32_t msm_rem_class(uint32_t len, uint32_t task_len) {
-  return (len * kRemClasses) / task_len;      // len < task_len -> 0 .. kRemClasses - 1
-}
-
-// class_total[c] = number of remainder tasks (cnt % task_len != 0) of relative-length class c
-static __global__ __launch_bounds__(256) void msm_rem_count_kernel(const uint32_t* __restrict__ cnt, uint32_t nbk,
-                                                            uint32_t tl, uint32_t* __restrict__ class_total) {
-  __builtin_amdgcn_s_setprio(3);   // issue priority over the throughput kernels sharing the SIMD (msm.cuh, kLatencyPrio)
-  __shared__ uint32_t h[kRemClasses];
-  if (threadIdx.x < kRemClasses) h[threadIdx.x] = 0;
-  __syncthreads();
-  const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
-  if (b < nbk) {
-    const uint32_t r = cnt[b] % tl;
-    if (r) atomicAdd(&h[msm_rem_class(r, tl)], 1u);
-  }
-  __syncthreads();
-  if (threadIdx.x < kRemClasses && h[threadIdx.x]) atomicAdd(&class_total[threadIdx.x], h[threadIdx.x]);
-}
 
 static __global__ __launch_bounds__(256) void msm_task_fill_kernel(const uint32_t* __restrict__ off,
                                                             const uint32_t* __restrict__ toff,
@@ -1123,8 +1121,7 @@ int msm_build_queue(const MsmGroup& g, MsmWorkspace* ws, MsmLaneWs& ln, hipStrea
                                           ln.d_toff + nbk, ln.d_foff + nbk, (uint32_t)ln.max_tasks,
                                           MsmSmallInit{ln.h_stat, ln.d_class, ln.d_queue, ln.d_heavy, ln.d_medium});
   msm_scan_apply_kernel<<<ntiles, 256, 0, st>>>(cnt, nbk, ln.task_len, ln.d_tile_a, ln.d_tile_b, ln.d_tile_c, off_base,
-                                                ln.d_queue, ln.d_off, ln.d_toff, ln.d_foff);
-  msm_rem_count_kernel<<<(nbk + 255) / 256, 256, 0, st>>>(cnt, nbk, ln.task_len, ln.d_class);
+                                                ln.d_queue, ln.d_off, ln.d_toff, ln.d_foff, ln.d_class);
   msm_task_fill_kernel<<<(nbk + 255) / 256, 256, 0, st>>>(ln.d_off, ln.d_toff, ln.d_foff, nbk, ln.task_len, ln.d_task_desc,
                                                           ln.d_qdesc, ln.d_class, ln.d_class + kRemClasses,
                                                           (uint32_t)ln.max_tasks);
