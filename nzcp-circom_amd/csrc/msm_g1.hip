@@ -940,7 +940,7 @@ static int lane_create(MsmLaneWs& ln, const MsmGroup& g, int curve, uint32_t key
   // dense rows: the scan-based reduce; sparse rows (witness lanes): r02's per-lane weighting (see msm.cuh).  G16_REDUCE_SCAN
   // = 0 / 1 forces one of them for every lane (sweeps).
   {
-    static const int force = getenv("G16_REDUCE_SCAN") ? atoi(getenv("G16_REDUCE_SCAN")) : -1;
+    const int force = getenv("G16_REDUCE_SCAN") ? atoi(getenv("G16_REDUCE_SCAN")) : -1;   // (read per handle: tests flip it)
     ln.reduce_scan = force < 0 ? g.dense : force != 0;
   }
   const MsmReducePlan rp = msm_reduce_plan(g, ln);

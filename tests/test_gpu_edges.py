@@ -221,3 +221,15 @@ def test_single_pass_binning_overflow_falls_back(amd, monkeypatch):
         proof, pub = prover.prove(f.write_wtns(w), f.le(7), f.le(9))
         assert proof == f.proof_obj(A, B, C)
     prover.close()
+
+
+@pytest.mark.parametrize("scan,c", [("1", 0), ("1", 7), ("1", 14), ("1", 17), ("0", 0), ("0", 9)])
+def test_both_bucket_reduces_on_every_lane(amd, monkeypatch, scan, c):
+    """The product picks the scan-based bucket reduce for dense rows and the per-lane weighting for the witness lanes'
+    sparse rows; G16_REDUCE_SCAN forces one of them everywhere.  Both must give the oracle's proof on every kind of row:
+    digit rows, the ones row, the salted top window (c = 7, 14), rows of one workgroup, rows cut into several workgroups
+    with the FINAL fold on the device (G2: 256-thread workgroups) and with the host fold of triples."""
+    zkb, wt, _ = amd.synth_setup(2500, 5, 2000, 41)
+    w = f.read_wtns(wt)["w"]
+    monkeypatch.setenv("G16_REDUCE_SCAN", scan)
+    _prove_both(amd, zkb, w, 7, 9, window_bits=c)
