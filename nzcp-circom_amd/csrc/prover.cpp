@@ -142,7 +142,7 @@ struct g16_prover {
     uint32_t* h_flag = nullptr;                           // ... its pinned host copy
     g16_timings tm{};
   };
-  static constexpr int kCtx = 3;   // at most; `nctx` are created
+  static constexpr int kCtx = 3;   // at most; `nctx` are created (a fourth context has to share hardware queues: r03, 272 proofs/s against 299)
   ProofCtx ctx[kCtx];
   int nctx = 3;   // r02 sweep, 512-proof batches: 205 / 257 / 267 proofs/s with 1 / 2 / 3 contexts (each on its own hardware queues)
   std::vector<Fr*> slot_dev;
