@@ -98,7 +98,7 @@ with open(os.path.join(prof, f"{tag}_pmc_accumulate.txt"), "w") as o:
                 f"active/wave_cyc={r.get('SQ_ACTIVE_INST_ANY', 0) / wc:.2f} wave_life={life:.2f}\n")
     o.write("# pass 1: FETCH_SIZE (KiB, raw)   pass 2: WRITE_SIZE (KiB), TCC_HIT_sum, TCC_MISS_sum\n")
     for a, b in zip(p1, p2):
-        if any(k in a["name"] for k in ("accumulate", "ntt_pass", "ntt_last", "bin_pass", "bin_sort", "qap_eval")):
+        if any(k in a["name"] for k in ("accumulate", "ntt_pass", "ntt_mid", "ntt_last", "bin_pass", "bin_direct", "bin_sort", "qap_eval", "qap_long")):
             o.write(f"{short(a['name']):44s} grid={a['grid']:8d} dur_ms={a['dur_ms']:.3f} FETCH_SIZE={a.get('FETCH_SIZE', 0):.4g} "
                     f"WRITE_SIZE={b.get('WRITE_SIZE', 0):.4g} TCC_HIT={b.get('TCC_HIT_sum', 0):.4g} TCC_MISS={b.get('TCC_MISS_sum', 0):.4g}\n")
 print(json.dumps(traffic, indent=1))
