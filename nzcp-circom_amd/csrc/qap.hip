@@ -25,12 +25,11 @@ __device__ __forceinline__ void qap_set_prio() {
   else if (p >= 3) __builtin_amdgcn_s_setprio(3);
 }
 
-__global__ __launch_bounds__(256) void qap_eval_kernel(
-    const uint32_t* __restrict__ rpA, const uint32_t* __restrict__ colA, const F29* __restrict__ valA,
+__device__ __forceinline__ void qap_eval_rows(
+    uint32_t block, const uint32_t* __restrict__ rpA, const uint32_t* __restrict__ colA, const F29* __restrict__ valA,
     const uint32_t* __restrict__ rpB, const uint32_t* __restrict__ colB, const F29* __restrict__ valB,
     const Fr* __restrict__ w, F29* __restrict__ a, F29* __restrict__ b, F29* __restrict__ cc, uint32_t N) {
-  qap_set_prio();
-  const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t c = block * blockDim.x + threadIdx.x;
   if (c >= N) return;
   if (rpA[c + 1] - rpA[c] > kQapLongRow || rpB[c + 1] - rpB[c] > kQapLongRow) return;   // qap_long_rows_kernel's
   // lazy sums: each term is below 1.1r; weak-reduce every 8 terms so the sum stays below 16r
@@ -65,13 +64,12 @@ __device__ __forceinline__ F29 f29_shfl_xor(const F29& v, int mask) {
 // whole wavefront per row (r02) those 48 k rows cost 65 M wavefront-instructions -- 4 % of a proof, two 6-step trees over
 // mostly empty lanes each; eight-lane groups do them for a tenth of that.
 template <int GW>
-__global__ __launch_bounds__(256) void qap_long_rows_kernel(
-    const uint32_t* __restrict__ rows, uint32_t n_long,
+__device__ __forceinline__ void qap_long_rows(
+    uint32_t block, const uint32_t* __restrict__ rows, uint32_t n_long,
     const uint32_t* __restrict__ rpA, const uint32_t* __restrict__ colA, const F29* __restrict__ valA,
     const uint32_t* __restrict__ rpB, const uint32_t* __restrict__ colB, const F29* __restrict__ valB,
     const Fr* __restrict__ w, F29* __restrict__ a, F29* __restrict__ b, F29* __restrict__ cc) {
-  qap_set_prio();
-  const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x, gid = tid / GW, lane = tid % GW;
+  const uint32_t tid = block * blockDim.x + threadIdx.x, gid = tid / GW, lane = tid % GW;
   if (gid >= n_long) return;   // (whole groups leave together: the shuffles below stay inside a group)
   const uint32_t c = rows[gid];
   F29 s[2] = {f29_zero(), f29_zero()};
@@ -98,22 +96,40 @@ __global__ __launch_bounds__(256) void qap_long_rows_kernel(
   }
 }
 
+// ONE launch for the three kinds of rows (they write disjoint rows and depend on nothing but the witness): blocks
+// [0, nb_long) take the rows above kQapWaveRow terms, a wavefront each -- first, they are the longest -- then nb_mid blocks
+// the rows of 17-64 terms in eight-lane groups, the rest a row per thread.  r02's three back-to-back launches at the head
+// of a proof's critical chain lasted 0.15 ms standalone; side by side they last as long as the longest.
+struct QapRows { const uint32_t* rows; uint32_t n_mid, n_long, nb_long, nb_mid; };
+__global__ __launch_bounds__(256) void qap_eval_kernel(
+    QapRows lr, const uint32_t* __restrict__ rpA, const uint32_t* __restrict__ colA, const F29* __restrict__ valA,
+    const uint32_t* __restrict__ rpB, const uint32_t* __restrict__ colB, const F29* __restrict__ valB,
+    const Fr* __restrict__ w, F29* __restrict__ a, F29* __restrict__ b, F29* __restrict__ cc, uint32_t N) {
+  qap_set_prio();
+  const uint32_t blk = blockIdx.x;   // (uniform per block: no divergence between the three bodies)
+  if (blk < lr.nb_long)
+    qap_long_rows<64>(blk, lr.rows + lr.n_mid, lr.n_long - lr.n_mid, rpA, colA, valA, rpB, colB, valB, w, a, b, cc);
+  else if (blk < lr.nb_long + lr.nb_mid)
+    qap_long_rows<8>(blk - lr.nb_long, lr.rows, lr.n_mid, rpA, colA, valA, rpB, colB, valB, w, a, b, cc);
+  else
+    qap_eval_rows(blk - lr.nb_long - lr.nb_mid, rpA, colA, valA, rpB, colB, valB, w, a, b, cc, N);
+}
+
 __global__ __launch_bounds__(256) void qap_convert_kernel(const Fr* __restrict__ in, F29* __restrict__ out, size_t n) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) out[i] = fr29_from_zkey_coef(in[i]);
 }
 
 int qap_eval(const QapCsr& q, const Fr* w_std, F29* a, F29* b, F29* cc, hipStream_t st) {
-  qap_eval_kernel<<<(q.N + 255) / 256, 256, 0, st>>>(q.row_ptr[0], q.col[0], q.val[0], q.row_ptr[1],
-                                                      q.col[1], q.val[1], w_std, a, b, cc, q.N);
   // long_rows = [the n_mid rows of kQapLongRow < terms <= kQapWaveRow][the rows above]
-  if (q.n_mid)
-    qap_long_rows_kernel<8><<<(q.n_mid + 31) / 32, 256, 0, st>>>(q.long_rows, q.n_mid, q.row_ptr[0], q.col[0], q.val[0],
-                                                                q.row_ptr[1], q.col[1], q.val[1], w_std, a, b, cc);
-  if (q.n_long > q.n_mid)
-    qap_long_rows_kernel<64><<<(q.n_long - q.n_mid + 3) / 4, 256, 0, st>>>(q.long_rows + q.n_mid, q.n_long - q.n_mid, q.row_ptr[0],
-                                                                          q.col[0], q.val[0], q.row_ptr[1], q.col[1], q.val[1],
-                                                                          w_std, a, b, cc);
+  QapRows lr;
+  lr.rows = q.long_rows;
+  lr.n_mid = q.n_mid;
+  lr.n_long = q.n_long;
+  lr.nb_long = (q.n_long - q.n_mid + 3) / 4;
+  lr.nb_mid = (q.n_mid + 31) / 32;
+  qap_eval_kernel<<<lr.nb_long + lr.nb_mid + (q.N + 255) / 256, 256, 0, st>>>(lr, q.row_ptr[0], q.col[0], q.val[0], q.row_ptr[1],
+                                                                              q.col[1], q.val[1], w_std, a, b, cc, q.N);
   G16_HIP(hipGetLastError());
   return G16_OK;
 }
