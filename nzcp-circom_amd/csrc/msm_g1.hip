@@ -195,6 +195,9 @@ static __global__ __launch_bounds__(kBinThreads) void msm_bin_pass_kernel(const 
 // over[0] and its entries are dropped -- msm_collect then repeats the launch on the two-pass path, which has no
 // capacity (degenerate scalar vectors: every P_i equal, say).  r02 timeline: pass 0 + its scans were 0.1 ms of the H
 // front end standalone, 0.2 ms in the product schedule, on the critical chain of a proof.
+// (WS: the window count as a compile-time constant -- 13 for the H-MSM at c = 20 -- so that the window loop unrolls and the LDS
+// atomics of a point's digits are in flight together instead of one at a time; 0 = run-time count)
+template <int WS>
 static __global__ __launch_bounds__(kBinThreads) void msm_bin_direct_kernel(const Fr* __restrict__ scalars,
                                                               const uint32_t* __restrict__ src, MsmPlan pl, U256 K,
                                                               uint32_t per, uint32_t cap, uint32_t* __restrict__ bin_cnt,
@@ -207,7 +210,7 @@ static __global__ __launch_bounds__(kBinThreads) void msm_bin_direct_kernel(cons
   const uint32_t lo = blockIdx.x * per;
   const uint32_t hi = (lo + per < pl.n) ? lo + per : pl.n;
   const uint32_t lowmask = (1u << pl.low_bits) - 1;
-  const uint32_t Ws = (uint32_t)pl.Ws;
+  const uint32_t Ws = WS ? (uint32_t)WS : (uint32_t)pl.Ws;
   for (int pass = 0; pass < 2; pass++) {
     for (uint32_t g = lo + threadIdx.x; g < hi; g += kBinThreads) {
       uint32_t sc[8];
@@ -215,7 +218,7 @@ static __global__ __launch_bounds__(kBinThreads) void msm_bin_direct_kernel(cons
       // every lane walks the windows in the same order (the rotation of msm_bin_pass_kernel spreads the LDS atomics of a
       // MULTI-row group over its rows; here the bins of a window are spread by the digits themselves), so the window's
       // offset, width and row are wave-uniform scalars
-      for (uint32_t j = 0; j < Ws; j++) {
+      auto digit = [&](uint32_t j) {
         const uint32_t wj = msm_win_bits(pl, j);
         const uint32_t e = msm_extract(sc, (int)msm_win_off(pl, j), (int)wj);
         const int32_t d = (j == Ws - 1) ? (int32_t)e : (int32_t)e - (int32_t)(1u << (wj - 1));
@@ -230,6 +233,12 @@ static __global__ __launch_bounds__(kBinThreads) void msm_bin_direct_kernel(cons
           if (pass && !(pos & 0x80000000u))
             tmp[pos] = make_uint2(eidx | (neg << 31), ((bucket & lowmask) << pl.wkb) | (j & ((1u << pl.wkb) - 1u)));
         }
+      };
+      if constexpr (WS > 0) {
+#pragma unroll
+        for (uint32_t j = 0; j < (uint32_t)WS; j++) digit(j);
+      } else {
+        for (uint32_t j = 0; j < Ws; j++) digit(j);
       }
     }
     __syncthreads();
@@ -1077,8 +1086,12 @@ int msm_front_end(const MsmGroup& g, MsmWorkspace* ws, const Fr* d_scalars, hipS
   }
   if (ws->direct) {
     G16_HIP(hipMemsetAsync(ws->d_bin_cnt, 0, (size_t)nrb * 4, st));
-    msm_bin_direct_kernel<<<g.chunks, kBinThreads, lds, st>>>(d_scalars, g.d_src, pl, K, g.per, ws->bin_cap, ws->d_bin_cnt,
-                                                             ws->h_over, ws->d_tmp);
+    if (g.Ws == 13)
+      msm_bin_direct_kernel<13><<<g.chunks, kBinThreads, lds, st>>>(d_scalars, g.d_src, pl, K, g.per, ws->bin_cap, ws->d_bin_cnt,
+                                                                   ws->h_over, ws->d_tmp);
+    else
+      msm_bin_direct_kernel<0><<<g.chunks, kBinThreads, lds, st>>>(d_scalars, g.d_src, pl, K, g.per, ws->bin_cap, ws->d_bin_cnt,
+                                                                  ws->h_over, ws->d_tmp);
     mark(0);
     mark(1);
     msm_bin_scan_kernel<<<1, 1024, 0, st>>>(ws->d_bin_cnt, nrb, ws->d_bin_start, ws->bin_cap);
