@@ -118,6 +118,7 @@ struct MsmConfig {
   int task_len = 0;    // max sorted entries per accumulation task (0 = default)
   bool dense = true;   // scalars uniform in Fr (H) vs NZCP witness mix (~1/3 full-width, ~30 % equal to 1)
   int precomp = 0;     // window precomputation factor of a single-section group (0 = auto, 1 = none): MsmGroup::pf
+  int dup_chunk = 0;   // bits per chunk of a repeated value (0 = kDupChunkBits): MsmGroup::dup_chunk
 };
 struct MsmWorkspace;   // opaque, msm.cuh
 static constexpr int kMsmMaxSections = 3;
@@ -179,6 +180,13 @@ struct MsmGroup {
   // chunk_k(s) T) and the host runs Horner over the 16 chunk sums.  dup_rows rows of B hash buckets follow the digit (+ ones) rows of every section.
   uint32_t dup_rows = 0;        // 0 = off
   uint32_t dup_bits = 0;        // log2(dup_rows * B) hash buckets per section
+  // a repeated value is cut into chunks of dup_chunk bits, one output row per chunk (dup_bit_rows of them); G16_DUP_CHUNK =
+  // 4 / 8 / 16 (sweeps).  8 bits halve the dependent steps per lane for twice the lanes: measured on the whole key and on
+  // shards of it (profiles/r03_sweeps.txt 10, 17), no gain either way
+  // dup_chunk = the window width when c <= 16 (then the chunk sums join the window sums and the host runs ONE Horner pass,
+  // msm_collect); dup_chunk_wide = 16, fewer rows of device work: the batch pipeline, which is device-bound, uses it
+  // (msm_set_dup_wide).  dup_rows_cap = the larger row count of the two (buffer sizes).
+  uint32_t dup_chunk = 16, dup_chunk_wide = 16, dup_rows_cap = 16;
   uint32_t rps = 0, rows = 0;   // rows per section (W + ones + dup_rows), rows in total
   uint32_t task_len = 0;        // of the G1 lane
   bool task_len_forced = false; // MsmConfig::task_len given: every lane uses it
@@ -202,8 +210,7 @@ struct MsmResult {
 };
 static constexpr uint32_t kDupMin = 8;       // points sharing a value before the dup row pays (1 entry + ~127 tree
                                              // additions per value against one entry per window)
-static constexpr uint32_t kDupChunkBits = 16; // a repeated value is cut into chunks of this many bits (8: measured in r03, profiles/r03_sweeps.txt) ...
-static constexpr uint32_t kDupBitRows = (254 + kDupChunkBits - 1) / kDupChunkBits;   // ... one output row per chunk
+static constexpr uint32_t kDupChunkBits = 16; // default chunk width of a repeated value (MsmGroup::dup_chunk)
 // msm_launch only enqueues: front end + G1 lane on `st`, the G2 lane (if any) forks onto `st2` after the sort
 // (st2 == nullptr or == st: same stream).  msm_collect waits for both, folds the window sums on the host
 // (Horner, c doublings per row) and fills `out`.  One launch in flight per workspace.
@@ -217,6 +224,7 @@ void msm_set_quota(MsmWorkspace* ws, uint32_t quota_g1, uint32_t quota_g2);   //
 hipEvent_t msm_event(MsmWorkspace* ws, int which);   // 0 = sort done, 1 / 2 = G1 accumulate kernel started / done, 3 / 4 = G1 / G2 lane done (nullptr: no such lane)
 int msm_collect(const MsmGroup& g, MsmWorkspace* ws, MsmResult* out);
 float msm_last_accum_ms(const MsmWorkspace* ws, int lane);        // lane 0 = G1, 1 = G2: the accumulate kernel alone
+void msm_set_dup_wide(MsmWorkspace* ws, const MsmGroup& g, bool wide);   // chunk width of the repeated values for the next launch (MsmGroup::dup_chunk / dup_chunk_wide)
 void msm_set_waves(MsmWorkspace* ws, uint32_t waves_g1, uint32_t waves_g2);   // persistent accumulate grids, wavefronts per SIMD (0 = full occupancy)
 float msm_event_offset_ms(MsmWorkspace* ws, hipEvent_t base, int lane, int which);   // G16_TRACE_HOST timeline
 
@@ -230,13 +238,13 @@ template <class F> inline void msm_combine_windows(XYZZ<F>& total, const XYZZ<F>
   }
   if (ones) xyzz_add(total, windows[W]);
 }
-// total += sum_k 2^(k L) * bits[k]  (the dup rows' chunk sums, L = kDupChunkBits: Horner, L doublings per row)
-template <class F> inline void msm_add_bit_sums(XYZZ<F>& total, const XYZZ<F>* bits) {
+// total += sum_k 2^(k L) * bits[k]  (the dup rows' chunk sums, L = chunk bits: Horner, L doublings per row)
+template <class F> inline void msm_add_bit_sums(XYZZ<F>& total, const XYZZ<F>* bits, uint32_t chunk_bits, uint32_t nrows) {
   XYZZ<F> acc;
   xyzz_set_inf(acc);
-  for (int b = (int)kDupBitRows - 1; b >= 0; b--) {
+  for (int b = (int)nrows - 1; b >= 0; b--) {
     if (!xyzz_is_inf(acc))
-      for (uint32_t k = 0; k < kDupChunkBits; k++) xyzz_dbl(acc);
+      for (uint32_t k = 0; k < chunk_bits; k++) xyzz_dbl(acc);
     xyzz_add(acc, bits[b]);
   }
   xyzz_add(total, acc);

@@ -116,7 +116,7 @@ struct MsmLaneWs {
   void* d_seg = nullptr;             // bucket reduce: one (V, W) pair per workgroup (rows cut into several workgroups)
   void* d_red = nullptr;             // sparse rows: ping-pong buffers of the tree over the segment sums
   bool reduce_scan = false;          // dense rows: msm_bucket_reduce_kernel (suffix scans); sparse rows: msm_bucket_reduce_mul_kernel
-  void* d_canon = nullptr;           // `rows` canonical XYZZ row sums, then nsec_lane * kDupBitRows chunk sums of the dup rows
+  void* d_canon = nullptr;           // `rows` canonical XYZZ row sums, then nsec_lane * dup_bit_rows chunk sums of the dup rows
   void* d_dseg = nullptr;            // dup rows: per (section, bit, chunk of 64 hash buckets) sums
   void* d_dred = nullptr;            // ... and their tree
   hipStream_t st_dup = nullptr;      // the dup-row stage runs beside the bucket reduce of the digit rows
@@ -153,6 +153,7 @@ struct MsmWorkspace {
   // single-pass front end (dense single-row groups, msm_bin_direct_kernel): (row, bin) regions of bin_cap entries in d_tmp
   bool direct = false;
   uint32_t bin_cap = 0;
+  uint32_t dup_chunk = 16, dup_bit_rows = 16;   // chunk width of the repeated values for the next launch (msm_set_dup_wide)
   uint32_t* h_over = nullptr;        // pinned: != 0 when a bin overflowed in the last launch (msm_collect repeats it two-pass)
   hipStream_t st_last = nullptr, st2_last = nullptr;   // streams of the running launch (for that repeat)
   MsmLaneWs lane[2];
@@ -810,11 +811,11 @@ static __global__ __launch_bounds__(256) void msm_dup_compact_kernel(const uint3
   dlist[((size_t)sl << dup_bits) + k] = hb;
 }
 
-// Step 2: dseg[(sl * kDupBitRows + k) * nchunk + chunk] = sum over the list entries [64 chunk, +64) of section sl of
-// (bits [k L, (k+1) L) of the entry's single scalar value) * (its bucket sum T), L = kDupChunkBits.  A lane multiplies
+// Step 2: dseg[(sl * bit_rows + k) * nchunk + chunk] = sum over the list entries [64 chunk, +64) of section sl of
+// (bits [k L, (k+1) L) of the entry's single scalar value) * (its bucket sum T), L = chunk_bits.  A lane multiplies
 // its own entry by the L-bit chunk (L doublings + ~L/2 additions), then one shuffle tree per wavefront; the host
 // weights row k with 2^(k L).  One wavefront per (sl, k, chunk); chunks beyond the list write infinity; the tree over
-// the chunks is msm_wave_reduce_kernel with kDupBitRows * nsec rows.  (First version: one row per BIT, a lane
+// the chunks is msm_wave_reduce_kernel with dup_bit_rows * nsec rows.  (First version: one row per BIT, a lane
 // contributing T when its value has the bit -- 254 trees per section instead of 16 short multiplications and 16
 // trees: 23 % of all VALU instructions of a proof, profiles/r02_pmc_accumulate.txt.)
 template <class F>
@@ -823,6 +824,7 @@ __global__ __launch_bounds__(kTailThreads) void msm_dup_bits_kernel(const XYZZ<F
                                                               const uint32_t* __restrict__ toff, uint32_t B,
                                                               uint32_t rps, uint32_t dup_row0, uint32_t dup_bits,
                                                               uint32_t sec0, uint32_t nsec_lane, uint32_t nchunk,
+                                                              uint32_t chunk_bits, uint32_t bit_rows,
                                                               const uint32_t* __restrict__ dcount,
                                                               const uint32_t* __restrict__ dlist,
                                                               const uint32_t* __restrict__ dup_rep,
@@ -834,9 +836,9 @@ __global__ __launch_bounds__(kTailThreads) void msm_dup_bits_kernel(const XYZZ<F
   // FIRST workgroups of the grid, spread over all CUs.  (Bit-major order put them at a fixed phase of every 64
   // consecutive workgroups, which the round-robin dispatch maps to the same few CUs: r02, 3.7 ms instead of 0.1.)
   const uint32_t wid = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), lane = threadIdx.x & 63u;
-  const uint32_t nrow = nsec_lane * kDupBitRows;
+  const uint32_t nrow = nsec_lane * bit_rows;
   if (wid >= nrow * nchunk) return;
-  const uint32_t chunk = wid / nrow, row = wid % nrow, bit = row % kDupBitRows, sl = row / kDupBitRows;
+  const uint32_t chunk = wid / nrow, row = wid % nrow, bit = row % bit_rows, sl = row / bit_rows;
   const uint32_t wave = row * nchunk + chunk;   // output slot: [(sl, bit)][chunk]
   const uint32_t count = dcount[sl], k = chunk * 64 + lane;
   XYZZ<F> acc;
@@ -845,11 +847,11 @@ __global__ __launch_bounds__(kTailThreads) void msm_dup_bits_kernel(const XYZZ<F
     if (k < count) {
       const uint32_t hb = dlist[((size_t)sl << dup_bits) + k];
       const Fr v = scalars[src[dup_rep[((size_t)(sec0 + sl) << dup_bits) + hb]]];
-      // this row's kDupChunkBits-bit chunk of the value times the bucket sum (short double-and-add)
-      const uint32_t pos = bit * kDupChunkBits;
+      // this row's chunk_bits-bit chunk of the value times the bucket sum (short double-and-add)
+      const uint32_t pos = bit * chunk_bits;
       uint64_t w2 = v.v[pos >> 5];
       if ((pos >> 5) + 1 < 8) w2 |= (uint64_t)v.v[(pos >> 5) + 1] << 32;
-      const uint32_t cv = (uint32_t)(w2 >> (pos & 31)) & ((1u << kDupChunkBits) - 1u);
+      const uint32_t cv = (uint32_t)(w2 >> (pos & 31)) & ((1u << chunk_bits) - 1u);
       if (cv) {
         const XYZZ<F> t = msm_bucket_value<F>(partial, bsum, toff, (sl * rps + dup_row0) * B + hb);
         msm_mul_small(acc, t, cv);
@@ -1065,7 +1067,7 @@ int msm_launch_lane_t(const MsmGroup& g, MsmWorkspace* ws, MsmLaneWs& ln, const 
     // lane starts at row sl * rps)
     // at most kDupChunks * 64 distinct repeated values per section take this path (more are simply left out of
     // the list... they cannot be: every qualifying bucket must be summed) -> the chunk count covers all buckets
-    const uint32_t nchunk = (1u << g.dup_bits) >> 6, drows = ln.nsec_lane * kDupBitRows;
+    const uint32_t nchunk = (1u << g.dup_bits) >> 6, drows = ln.nsec_lane * ws->dup_bit_rows;
     const uint32_t waves_d = drows * nchunk;
     const uint32_t sec0 = ln.key_lo / (g.rps * g.B), dup_row0 = (uint32_t)g.W + (g.ones ? 1u : 0u);
     G16_HIP(hipMemsetAsync(ln.d_dcount, 0, 16, sd));
@@ -1073,7 +1075,7 @@ int msm_launch_lane_t(const MsmGroup& g, MsmWorkspace* ws, MsmLaneWs& ln, const 
         ln.d_toff, g.B, g.rps, dup_row0, g.dup_bits, sec0, ln.nsec_lane, ws->d_dup_cnt, ws->d_dup_mixed, ln.d_dcount, ln.d_dlist);
     msm_dup_bits_kernel<FT><<<(waves_d + 3) / 4, kTailThreads, 0, sd>>>(
         (const TPT*)ln.d_partial, (const TPT*)ln.d_bsum, ln.d_toff, g.B, g.rps, dup_row0, g.dup_bits, sec0, ln.nsec_lane, nchunk,
-        ln.d_dcount, ln.d_dlist, ws->d_dup_rep, ws->d_scalars, g.d_src, (TPT*)ln.d_dseg);
+        ws->dup_chunk, ws->dup_bit_rows, ln.d_dcount, ln.d_dlist, ws->d_dup_rep, ws->d_scalars, g.d_src, (TPT*)ln.d_dseg);
     TPT* dcur = (TPT*)ln.d_dseg;
     uint32_t dcnt = nchunk;
     TPT* dbufs[2] = {(TPT*)ln.d_dred, (TPT*)ln.d_dred + (size_t)drows * ((nchunk + 63) / 64)};

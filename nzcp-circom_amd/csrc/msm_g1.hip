@@ -822,6 +822,14 @@ int msm_group_create(MsmGroup& g, const MsmSectionIn* secs, int nsec, const MsmC
       g.dup_rows = g.B >= 16384 ? 1u : 16384u / g.B;
       g.dup_bits = 0;
       while ((1u << g.dup_bits) < g.dup_rows * g.B) g.dup_bits++;
+      // chunk width = window width (c <= 16): chunk k of a repeated value then weighs 2^(c k) like window k, its sum joins
+      // the window's row sum on the host and ONE Horner pass does for both (msm_collect) -- r03: the host's share of a
+      // proof was 0.8 ms, half of it the 240 doublings per section and curve of a second Horner over 16-bit chunks
+      int ch = cfg.dup_chunk ? cfg.dup_chunk : (g.c <= 16 ? g.c : (int)kDupChunkBits);
+      if (const char* e = getenv("G16_DUP_CHUNK")) ch = atoi(e);
+      if (ch >= 2 && ch <= 16) g.dup_chunk = (uint32_t)ch;
+      g.dup_chunk_wide = (getenv("G16_DUP_CHUNK") || cfg.dup_chunk) ? g.dup_chunk : (uint32_t)kDupChunkBits;
+      g.dup_rows_cap = (254 + std::min(g.dup_chunk, g.dup_chunk_wide) - 1) / std::min(g.dup_chunk, g.dup_chunk_wide);
     }
   }
   g.rps = (uint32_t)g.W + (g.ones ? 1u : 0u) + g.dup_rows;
@@ -964,7 +972,7 @@ static int lane_create(MsmLaneWs& ln, const MsmGroup& g, int curve, uint32_t key
   ln.row_pts = ln.reduce_scan ? ln.rows * msm_row_out_points(rp) : ln.rows;
   size_t out_pts = ln.row_pts;
   if (g.dup_rows) {
-    const size_t nchunk = ((size_t)1 << g.dup_bits) >> 6, drows = (size_t)ln.nsec_lane * kDupBitRows;
+    const size_t nchunk = ((size_t)1 << g.dup_bits) >> 6, drows = (size_t)ln.nsec_lane * g.dup_rows_cap;
     out_pts += drows;
     G16_HIP(hipMalloc(&ln.d_dseg, drows * nchunk * pb + 256));
     G16_HIP(hipMalloc(&ln.d_dred, 2 * drows * ((nchunk + 63) / 64) * pb + 256));
@@ -1008,6 +1016,7 @@ int msm_workspace_create(MsmWorkspace** out, const MsmGroup& g) {
   MsmWorkspace* ws = new MsmWorkspace();
   *out = ws;
   if (g.n == 0) return G16_OK;
+  msm_set_dup_wide(ws, g, false);
   const uint32_t nrb = g.rows * g.bins;
   ws->nb = g.rows * g.B;
   G16_HIP(hipMalloc(&ws->d_hist, ((size_t)g.chunks * nrb + 4) * 4));
@@ -1221,9 +1230,18 @@ int msm_collect(const MsmGroup& g, MsmWorkspace* ws, MsmResult* out) {
           msm_fold_row<FqOps>(folded[r], rows + (size_t)r * ngroups * 3, ngroups, rp, msm_row_kind(rp, r));
       }
       const G1XYZZ* rsum = !folded.empty() ? folded.data() : rows;
+      const bool merged = g.dup_rows && ws->dup_chunk == (uint32_t)g.c && ws->dup_bit_rows == (uint32_t)g.W;
+      std::vector<G1XYZZ> wrow;
       for (int s = 0; s < g.nsec; s++) {
-        msm_combine_windows<FqOps>(out->g1[s], rsum + (size_t)s * g.rps, g.W, g.c, g.ones);
-        if (g.dup_rows) msm_add_bit_sums<FqOps>(out->g1[s], rows + ln.row_pts + (size_t)s * kDupBitRows);
+        const G1XYZZ* rs = rsum + (size_t)s * g.rps;
+        const G1XYZZ* dup = rows + ln.row_pts + (size_t)s * ws->dup_bit_rows;
+        if (merged) {   // chunk k of the repeated values weighs like window k: one Horner pass
+          wrow.assign(rs, rs + g.W + (g.ones ? 1 : 0));
+          for (int j = 0; j < g.W; j++) xyzz_add(wrow[j], dup[j]);
+          rs = wrow.data();
+        }
+        msm_combine_windows<FqOps>(out->g1[s], rs, g.W, g.c, g.ones);
+        if (g.dup_rows && !merged) msm_add_bit_sums<FqOps>(out->g1[s], dup, ws->dup_chunk, ws->dup_bit_rows);
       }
     } else {
       const G2XYZZ* rows = reinterpret_cast<const G2XYZZ*>(ln.h_pinned);
@@ -1234,8 +1252,15 @@ int msm_collect(const MsmGroup& g, MsmWorkspace* ws, MsmResult* out) {
           msm_fold_row<Fq2Ops>(folded[r], rows + (size_t)r * ngroups * 3, ngroups, rp, msm_row_kind(rp, r));
       }
       const G2XYZZ* rsum = !folded.empty() ? folded.data() : rows;
+      const bool merged = g.dup_rows && ws->dup_chunk == (uint32_t)g.c && ws->dup_bit_rows == (uint32_t)g.W;
+      std::vector<G2XYZZ> wrow;
+      if (merged) {
+        wrow.assign(rsum, rsum + g.W + (g.ones ? 1 : 0));
+        for (int j = 0; j < g.W; j++) xyzz_add(wrow[j], rows[ln.row_pts + j]);
+        rsum = wrow.data();
+      }
       msm_combine_windows<Fq2Ops>(out->g2, rsum, g.W, g.c, g.ones);
-      if (g.dup_rows) msm_add_bit_sums<Fq2Ops>(out->g2, rows + ln.row_pts);
+      if (g.dup_rows && !merged) msm_add_bit_sums<Fq2Ops>(out->g2, rows + ln.row_pts, ws->dup_chunk, ws->dup_bit_rows);
     }
   }
   if (overflow) return G16_E_STATE;
@@ -1253,6 +1278,11 @@ int msm_collect(const MsmGroup& g, MsmWorkspace* ws, MsmResult* out) {
 }
 
 float msm_last_accum_ms(const MsmWorkspace* ws, int lane) { return ws->lane[lane & 1].last_accum_ms; }
+void msm_set_dup_wide(MsmWorkspace* ws, const MsmGroup& g, bool wide) {
+  if (!ws) return;
+  ws->dup_chunk = wide ? g.dup_chunk_wide : g.dup_chunk;
+  ws->dup_bit_rows = (254 + ws->dup_chunk - 1) / ws->dup_chunk;
+}
 void msm_set_waves(MsmWorkspace* ws, uint32_t waves_g1, uint32_t waves_g2) {
   ws->lane[0].waves_per_simd = waves_g1;
   ws->lane[1].waves_per_simd = waves_g2;

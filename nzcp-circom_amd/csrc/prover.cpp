@@ -677,9 +677,13 @@ static int launch_h_lanes(g16_prover* P, ProofCtx& c, bool w_launched) {
   G16_HIP(hipEventRecord(c.mev[1][1], c.st));
   return G16_OK;
 }
-static int launch_ctx(g16_prover* P, ProofCtx& c, const Fr* d_w) {
+// `pipelined`: one of several proofs in flight (g16_prove_batch) -- the device is then the bottleneck, not the host's
+// share of one proof, and the repeated-value stage runs in its cheaper-on-the-device form (MsmGroup::dup_chunk_wide)
+static int launch_ctx(g16_prover* P, ProofCtx& c, const Fr* d_w, bool pipelined = false) {
   G16_HIP(hipSetDevice(P->device));
   int rc;
+  msm_set_dup_wide(c.ws[0], P->grp[0], pipelined);
+  if (P->b2_solo) msm_set_dup_wide(c.ws[2], P->grp[2], pipelined);
   const auto th0 = std::chrono::steady_clock::now();
   G16_HIP(hipEventRecord(c.ev[2], c.st));
   // critical chain first (host launch order matters: the witness group's ~35 launches cost host time)
@@ -1051,7 +1055,7 @@ int g16_prove_batch(g16_prover* p, const uint8_t* const* wtns, const size_t* wtn
     const double t_c = now_ms();
     if ((rc = qap_check_witness(c.d_w, p->nVars, c.d_flag, c.h_flag, c.st))) return rc;
     if (pub && p->nPublic) memcpy(pub + i * (size_t)p->nPublic * 32, body + 32, (size_t)p->nPublic * 32);
-    if ((rc = launch_ctx(p, c, c.d_w))) return rc;
+    if ((rc = launch_ctx(p, c, c.d_w, count > 1))) return rc;
     const double t_d = now_ms();
     bl_rc[i % nctx] = prepare_blinding(&p->kp, rs ? rs + i * 64 : nullptr, rs ? rs + i * 64 + 32 : nullptr,
                                                     bl[i % nctx]);
