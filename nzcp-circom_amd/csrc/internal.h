@@ -191,6 +191,7 @@ struct MsmGroup {
   uint32_t task_len = 0;        // of the G1 lane
   bool task_len_forced = false; // MsmConfig::task_len given: every lane uses it
   bool dense = true;
+  bool src_identity = false;   // point g takes scalar g (no infinity points dropped, no offset): the front end skips d_src
   uint32_t chunks = 1, per = 0; // front-end geometry: workgroups over the points, points per workgroup
   uint64_t max_entries = 0;     // upper bound on sorted entries of one launch
 };
@@ -223,6 +224,7 @@ int msm_launch_lanes(const MsmGroup& g, MsmWorkspace* ws, hipStream_t st, hipStr
 void msm_set_quota(MsmWorkspace* ws, uint32_t quota_g1, uint32_t quota_g2);   // accumulate wavefronts retire after this many chunks of 64 tasks (0 = persistent)
 hipEvent_t msm_event(MsmWorkspace* ws, int which);   // 0 = sort done, 1 / 2 = G1 accumulate kernel started / done, 3 / 4 = G1 / G2 lane done (nullptr: no such lane)
 int msm_collect(const MsmGroup& g, MsmWorkspace* ws, MsmResult* out);
+double trace_ms();   // G16_TRACE_HOST: milliseconds since the last proof was launched (prover.cpp)
 float msm_last_accum_ms(const MsmWorkspace* ws, int lane);        // lane 0 = G1, 1 = G2: the accumulate kernel alone
 void msm_set_dup_wide(MsmWorkspace* ws, const MsmGroup& g, bool wide);   // chunk width of the repeated values for the next launch (MsmGroup::dup_chunk / dup_chunk_wide)
 void msm_set_waves(MsmWorkspace* ws, uint32_t waves_g1, uint32_t waves_g2);   // persistent accumulate grids, wavefronts per SIMD (0 = full occupancy)

@@ -125,6 +125,7 @@ struct MsmLaneWs {
   uint32_t* d_dlist = nullptr;       // [nsec_lane][2^dup_bits] their hash-bucket ids, compacted
   uint32_t nsec_lane = 0;            // sections this lane covers (G1: all, G2: one)
   uint8_t* h_pinned = nullptr;
+  bool rows_mapped = false;          // d_canon IS h_pinned seen from the device (lane_create)
   size_t out_bytes = 0;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;   // around the bucket-accumulate kernel
   hipEvent_t ev_done = nullptr;
@@ -1134,7 +1135,7 @@ int msm_launch_lane_t(const MsmGroup& g, MsmWorkspace* ws, MsmLaneWs& ln, const 
   }
   G16_HIP(hipGetLastError());
   if (g.dup_rows && ln.st_dup) G16_HIP(hipStreamWaitEvent(st, ln.ev_dup_join, 0));
-  G16_HIP(hipMemcpyAsync(ln.h_pinned, ln.d_canon, (size_t)nout_pts * sizeof(CPT), hipMemcpyDeviceToHost, st));
+  if (!ln.rows_mapped) G16_HIP(hipMemcpyAsync(ln.h_pinned, ln.d_canon, (size_t)nout_pts * sizeof(CPT), hipMemcpyDeviceToHost, st));
   mark(3);
   G16_HIP(hipEventRecord(ln.ev_done, st));
   return G16_OK;

@@ -20,7 +20,7 @@ __device__ __forceinline__ uint32_t msm_extract(const uint32_t s[8], int pos, in
 // Loads the scalar of point g, adds K; returns true when the scalar is exactly 1.  *bits (optional) <- bit length of the scalar.
 __device__ __forceinline__ bool msm_load_scalar(const Fr* __restrict__ scalars, const uint32_t* __restrict__ src,
                                                 uint32_t g, const U256& K, uint32_t s[8], uint32_t* bits = nullptr) {
-  const Fr x = scalars[src[g]];
+  const Fr x = scalars[src ? src[g] : g];   // (src == nullptr: the identity map)
   uint32_t hi = 0;
 #pragma unroll
   for (int k = 1; k < 8; k++) hi |= x.v[k];
@@ -211,10 +211,23 @@ static __global__ __launch_bounds__(kBinThreads) void msm_bin_direct_kernel(cons
   const uint32_t hi = (lo + per < pl.n) ? lo + per : pl.n;
   const uint32_t lowmask = (1u << pl.low_bits) - 1;
   const uint32_t Ws = WS ? (uint32_t)WS : (uint32_t)pl.Ws;
-  for (int pass = 0; pass < 2; pass++) {
-    for (uint32_t g = lo + threadIdx.x; g < hi; g += kBinThreads) {
-      uint32_t sc[8];
-      (void)msm_load_scalar(scalars, src, g, K, sc);
+  // pass 0 counts (LDS atomics WITHOUT a return value: fire and forget), pass 1 takes positions (returning atomics) and scatters
+  auto sweep = [&](auto pass_tag) {
+    constexpr bool kScatter = decltype(pass_tag)::value;
+    // four points per lane and trip: their scalar loads (two dependent ones each when the group has a point map) are in
+    // flight together -- the kernel runs one wavefront per SIMD and its time was the sum of those latencies
+    for (uint32_t g0 = lo + threadIdx.x; g0 < hi; g0 += 4 * kBinThreads) {
+      uint32_t scq[4][8];
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        const uint32_t gq = g0 + (uint32_t)q * kBinThreads;
+        (void)msm_load_scalar(scalars, src, gq < hi ? gq : g0, K, scq[q]);
+      }
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+      const uint32_t g = g0 + (uint32_t)q * kBinThreads;
+      if (g >= hi) break;
+      const uint32_t (&sc)[8] = scq[q];
       // every lane walks the windows in the same order (the rotation of msm_bin_pass_kernel spreads the LDS atomics of a
       // MULTI-row group over its rows; here the bins of a window are spread by the digits themselves), so the window's
       // offset, width and row are wave-uniform scalars
@@ -227,11 +240,15 @@ static __global__ __launch_bounds__(kBinThreads) void msm_bin_direct_kernel(cons
           uint32_t bucket = (d < 0 ? (uint32_t)(-d) : (uint32_t)d) - 1u;
           if (pl.salt_bits && j == Ws - 1) bucket = (bucket << pl.salt_bits) | (g & ((1u << pl.salt_bits) - 1));
           const uint32_t r = pl.pf > 1 ? j % pl.W : j;
-          const uint32_t eidx = pl.pf > 1 ? (j / pl.W) * pl.n + g : g;
           const uint32_t rb = r * pl.bins + (bucket >> pl.low_bits);
-          const uint32_t pos = atomicAdd(&lds[rb], 1u);
-          if (pass && !(pos & 0x80000000u))
-            tmp[pos] = make_uint2(eidx | (neg << 31), ((bucket & lowmask) << pl.wkb) | (j & ((1u << pl.wkb) - 1u)));
+          if constexpr (!kScatter) {
+            __hip_atomic_fetch_add(&lds[rb], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          } else {
+            const uint32_t eidx = pl.pf > 1 ? (j / pl.W) * pl.n + g : g;
+            const uint32_t pos = atomicAdd(&lds[rb], 1u);
+            if (!(pos & 0x80000000u))
+              tmp[pos] = make_uint2(eidx | (neg << 31), ((bucket & lowmask) << pl.wkb) | (j & ((1u << pl.wkb) - 1u)));
+          }
         }
       };
       if constexpr (WS > 0) {
@@ -240,23 +257,24 @@ static __global__ __launch_bounds__(kBinThreads) void msm_bin_direct_kernel(cons
       } else {
         for (uint32_t j = 0; j < Ws; j++) digit(j);
       }
-    }
-    __syncthreads();
-    if (!pass) {
-      // claim: lds[b] <- where this workgroup's run of bin b starts (bit 31: the bin is full, its entries are dropped)
-      for (uint32_t b = threadIdx.x; b < nrb; b += kBinThreads) {
-        const uint32_t c = lds[b];
-        uint32_t start = 0x80000000u;
-        if (c) {
-          const uint32_t at = atomicAdd(&bin_cnt[b], c);
-          if (at + c <= cap) start = b * cap + at;
-          else over[0] = 1u;
-        }
-        lds[b] = start;
       }
-      __syncthreads();
     }
+  };
+  sweep(std::false_type{});
+  __syncthreads();
+  // claim: lds[b] <- where this workgroup's run of bin b starts (bit 31: the bin is full, its entries are dropped)
+  for (uint32_t b = threadIdx.x; b < nrb; b += kBinThreads) {
+    const uint32_t c = lds[b];
+    uint32_t start = 0x80000000u;
+    if (c) {
+      const uint32_t at = atomicAdd(&bin_cnt[b], c);
+      if (at + c <= cap) start = b * cap + at;
+      else over[0] = 1u;
+    }
+    lds[b] = start;
   }
+  __syncthreads();
+  sweep(std::true_type{});
 }
 
 // One wavefront per (row, bin): exclusive scan of its per-chunk counts in place (the run starts of pass 1,
@@ -752,6 +770,8 @@ int msm_group_create(MsmGroup& g, const MsmSectionIn* secs, int nsec, const MsmC
   }
   for (int s = nsec; s < kMsmMaxSections; s++) g.sec_begin[s] = (uint32_t)src.size();
   g.n = (uint32_t)src.size();
+  g.src_identity = true;
+  for (size_t k = 0; k < src.size() && g.src_identity; k++) g.src_identity = (src[k] == (uint32_t)k);
   if (g2_sec >= 0 && g.sec_n[g2_sec] == 0) g2_sec = -1;   // nothing rides: the G2 sum is the point at infinity
   g.g2_sec = g2_sec;
   if (g.n >= 0x40000000u) { set_error("msm: too many bases"); return G16_E_ARG; }
@@ -989,7 +1009,12 @@ static int lane_create(MsmLaneWs& ln, const MsmGroup& g, int curve, uint32_t key
   }
   ln.out_bytes = out_pts * cpb;
   G16_HIP(hipHostMalloc((void**)&ln.h_pinned, ln.out_bytes + 256));
-  G16_HIP(hipMalloc(&ln.d_canon, ln.out_bytes + 256));
+  // the last kernels of a lane write their few KB of row sums straight into the pinned host block (it is mapped into the
+  // device's address space): no copy-engine hop between the last kernel and the host's wake-up.  G16_ROWS_COPY=1: r02's
+  // device buffer + hipMemcpyAsync
+  ln.rows_mapped = !(getenv("G16_ROWS_COPY") && atoi(getenv("G16_ROWS_COPY")));
+  if (ln.rows_mapped) G16_HIP(hipHostGetDevicePointer(&ln.d_canon, ln.h_pinned, 0));
+  else G16_HIP(hipMalloc(&ln.d_canon, ln.out_bytes + 256));
   G16_HIP(hipEventCreate(&ln.ev0));
   G16_HIP(hipEventCreate(&ln.ev1));
   G16_HIP(hipEventCreate(&ln.ev_done));
@@ -998,7 +1023,7 @@ static int lane_create(MsmLaneWs& ln, const MsmGroup& g, int curve, uint32_t key
 
 static void lane_destroy(MsmLaneWs& ln) {
   void* ptrs[] = {ln.d_task_desc, ln.d_qdesc, ln.d_class, ln.d_queue, ln.d_redo, ln.d_partial, ln.d_bsum, ln.d_heavy, ln.d_medium,
-                  ln.d_seg, ln.d_red, ln.d_canon, ln.d_off, ln.d_toff, ln.d_foff, ln.d_tile_a, ln.d_tile_b, ln.d_tile_c,
+                  ln.d_seg, ln.d_red, ln.rows_mapped ? nullptr : ln.d_canon, ln.d_off, ln.d_toff, ln.d_foff, ln.d_tile_a, ln.d_tile_b, ln.d_tile_c,
                   ln.d_dseg, ln.d_dred, ln.d_dcount, ln.d_dlist};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
@@ -1096,10 +1121,10 @@ int msm_front_end(const MsmGroup& g, MsmWorkspace* ws, const Fr* d_scalars, hipS
   if (ws->direct) {
     G16_HIP(hipMemsetAsync(ws->d_bin_cnt, 0, (size_t)nrb * 4, st));
     if (g.Ws == 13)
-      msm_bin_direct_kernel<13><<<g.chunks, kBinThreads, lds, st>>>(d_scalars, g.d_src, pl, K, g.per, ws->bin_cap, ws->d_bin_cnt,
+      msm_bin_direct_kernel<13><<<g.chunks, kBinThreads, lds, st>>>(d_scalars, g.src_identity ? nullptr : g.d_src, pl, K, g.per, ws->bin_cap, ws->d_bin_cnt,
                                                                    ws->h_over, ws->d_tmp);
     else
-      msm_bin_direct_kernel<0><<<g.chunks, kBinThreads, lds, st>>>(d_scalars, g.d_src, pl, K, g.per, ws->bin_cap, ws->d_bin_cnt,
+      msm_bin_direct_kernel<0><<<g.chunks, kBinThreads, lds, st>>>(d_scalars, g.src_identity ? nullptr : g.d_src, pl, K, g.per, ws->bin_cap, ws->d_bin_cnt,
                                                                   ws->h_over, ws->d_tmp);
     mark(0);
     mark(1);
@@ -1206,6 +1231,8 @@ int msm_collect(const MsmGroup& g, MsmWorkspace* ws, MsmResult* out) {
     MsmLaneWs& ln = ws->lane[l];
     if (!ln.active) continue;
     G16_HIP(hipEventSynchronize(ln.ev_done));
+    static const bool trace = getenv("G16_TRACE_HOST") != nullptr;
+    if (trace) fprintf(stderr, "[g16 tail] %s lane %d: host saw its row sums at %.3f ms\n", g.dup_rows ? "W" : "H", l, trace_ms());
     (void)hipEventElapsedTime(&ln.last_accum_ms, ln.ev0, ln.ev1);
     if (ln.h_stat[2] || ln.h_stat[3]) {   // (checked on the device, msm_scan_top_kernel / msm_combine_light_kernel)
       set_error(ln.h_stat[2] ? "msm: lane " + std::to_string(l) + " needed " + std::to_string(ln.h_stat[2]) +

@@ -147,7 +147,8 @@ struct g16_prover {
   int nctx = 3;   // r02 sweep, 512-proof batches: 205 / 257 / 267 proofs/s with 1 / 2 / 3 contexts (each on its own hardware queues)
   std::vector<Fr*> slot_dev;
   std::vector<std::vector<uint8_t>> slot_pub;
-  g16_timings tm{};    // of the last completed proof
+  g16_timings tm{};    // of the last completed proof (refresh_timings)
+  int tm_ctx = -1;     // context whose events hold newer timings than `tm`, or -1
   std::mutex mu;
 
   ~g16_prover() {
@@ -583,6 +584,17 @@ static void trace_host(const char* what, const std::chrono::steady_clock::time_p
     fprintf(stderr, "[g16 host] %s enqueued at %.3f ms\n", what,
             std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
 }
+// ... and the host's second half of a proof (waits, folds, assembly) on the same clock: origin = the last launch_ctx
+static std::chrono::steady_clock::time_point g_trace_origin;
+namespace g16 {
+double trace_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - g_trace_origin).count(); }
+}
+static void trace_tail(const char* what) {
+  static const bool on = getenv("G16_TRACE_HOST") != nullptr;
+  if (on)
+    fprintf(stderr, "[g16 tail] %s at %.3f ms\n", what,
+            std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - g_trace_origin).count());
+}
 // Scheduling knobs (sweeps; the defaults are the measured optimum):
 //   G16_ACC_WAVES = "abc": wavefronts per SIMD of the persistent accumulate grids of the witness G1 lane, the
 //                   witness G2 lane and the H-MSM (0 = the kernel's full occupancy)
@@ -675,6 +687,7 @@ static int launch_h_lanes(g16_prover* P, ProofCtx& c, bool w_launched) {
   hipEvent_t gate = (hg >= 1 && P->grp[0].n) ? msm_event(c.ws[0], 4) : nullptr;
   if ((rc = msm_launch_lanes(P->grp[1], c.ws[1], c.st, c.st, gate, nullptr))) return rc;
   G16_HIP(hipEventRecord(c.mev[1][1], c.st));
+  G16_HIP(hipEventRecord(c.ev[5], c.st));   // end of the main stream's share of this proof (refresh_timings)
   return G16_OK;
 }
 // `pipelined`: one of several proofs in flight (g16_prove_batch) -- the device is then the bottleneck, not the host's
@@ -685,6 +698,8 @@ static int launch_ctx(g16_prover* P, ProofCtx& c, const Fr* d_w, bool pipelined 
   msm_set_dup_wide(c.ws[0], P->grp[0], pipelined);
   if (P->b2_solo) msm_set_dup_wide(c.ws[2], P->grp[2], pipelined);
   const auto th0 = std::chrono::steady_clock::now();
+  g_trace_origin = th0;
+  if (P->tm_ctx == (int)(&c - P->ctx)) P->tm_ctx = -1;   // (its events are about to be recorded again)
   G16_HIP(hipEventRecord(c.ev[2], c.st));
   // critical chain first (host launch order matters: the witness group's ~35 launches cost host time)
   static const bool fuse = !(getenv("G16_NO_FUSED_JOIN") && atoi(getenv("G16_NO_FUSED_JOIN")));
@@ -704,33 +719,13 @@ static int launch_ctx(g16_prover* P, ProofCtx& c, const Fr* d_w, bool pipelined 
   return G16_OK;
 }
 
-// Wait for context `c` and fold each MSM's row sums, in two halves: the witness group (A, B1, B2, C finish
-// long before the H-MSM), then H.  The caller does the H-independent part of the proof assembly between the two.
-static int collect_witness_msms(g16_prover* P, ProofCtx& c, Partial& out) {
-  MsmResult r;
-  int rc = msm_collect(P->grp[0], c.ws[0], &r);
-  if (rc) return rc;
-  out.A = r.g1[0];
-  out.B1 = r.g1[1];
-  out.C = r.g1[2];
-  out.B2 = r.g2;
-  c.tm.msm_accum_kernel_ms[0] = msm_last_accum_ms(c.ws[0], 0);
-  c.tm.msm_accum_kernel_ms[1] = c.tm.msm_accum_kernel_ms[3] = 0.f;
-  c.tm.msm_accum_kernel_ms[2] = msm_last_accum_ms(c.ws[0], 1);
-  if (P->b2_solo) {
-    if ((rc = msm_collect(P->grp[2], c.ws[2], &r))) return rc;
-    out.B2 = r.g2;
-    c.tm.msm_accum_kernel_ms[2] = msm_last_accum_ms(c.ws[2], 1);
-  }
-  return G16_OK;
-}
-static int collect_h_msm(g16_prover* P, ProofCtx& c, Partial& out) {
-  MsmResult r;
-  int rc = msm_collect(P->grp[1], c.ws[1], &r);
-  if (rc) return rc;
-  out.H = r.g1[0];
-  c.tm.msm_accum_kernel_ms[4] = msm_last_accum_ms(c.ws[1], 0);
-  G16_HIP(hipEventRecord(c.ev[5], c.st));
+// Stream timings of the last collected proof, from the events its launch recorded (c.ev[5] closes the main stream in
+// launch_h_lanes); valid until that context launches its next proof
+static int refresh_timings(g16_prover* P) {
+  if (P->tm_ctx < 0) return G16_OK;
+  ProofCtx& c = P->ctx[P->tm_ctx];
+  P->tm_ctx = -1;
+  G16_HIP(hipSetDevice(P->device));
   G16_HIP(hipEventSynchronize(c.ev[5]));
   if (c.wst != c.st) G16_HIP(hipStreamSynchronize(c.wst));
   if (c.wst2 != c.st) G16_HIP(hipStreamSynchronize(c.wst2));
@@ -769,6 +764,42 @@ static int collect_h_msm(g16_prover* P, ProofCtx& c, Partial& out) {
   P->tm.upload_ms = up;
   return G16_OK;
 }
+
+// Wait for context `c` and fold each MSM's row sums, in two halves: the witness group (A, B1, B2, C finish
+// long before the H-MSM), then H.  The caller does the H-independent part of the proof assembly between the two.
+static int collect_witness_msms(g16_prover* P, ProofCtx& c, Partial& out) {
+  MsmResult r;
+  int rc = msm_collect(P->grp[0], c.ws[0], &r);
+  if (rc) return rc;
+  out.A = r.g1[0];
+  out.B1 = r.g1[1];
+  out.C = r.g1[2];
+  out.B2 = r.g2;
+  c.tm.msm_accum_kernel_ms[0] = msm_last_accum_ms(c.ws[0], 0);
+  c.tm.msm_accum_kernel_ms[1] = c.tm.msm_accum_kernel_ms[3] = 0.f;
+  c.tm.msm_accum_kernel_ms[2] = msm_last_accum_ms(c.ws[0], 1);
+  if (P->b2_solo) {
+    if ((rc = msm_collect(P->grp[2], c.ws[2], &r))) return rc;
+    out.B2 = r.g2;
+    c.tm.msm_accum_kernel_ms[2] = msm_last_accum_ms(c.ws[2], 1);
+  }
+  return G16_OK;
+}
+static int collect_h_msm(g16_prover* P, ProofCtx& c, Partial& out) {
+  MsmResult r;
+  int rc = msm_collect(P->grp[1], c.ws[1], &r);
+  if (rc) return rc;
+  out.H = r.g1[0];
+  trace_tail("H sum folded");
+  c.tm.msm_accum_kernel_ms[4] = msm_last_accum_ms(c.ws[1], 0);
+  // the stream timings of this proof are read from its events when somebody asks (g16_get_timings): the record +
+  // synchronise + eight elapsed-time queries cost 0.05 ms of every proof when they sat here (r03 host trace).  The
+  // streams need no draining either: each lane's ev_done, just waited for, is the last work on its stream.
+  P->tm_ctx = (int)(&c - P->ctx);
+  static const bool trace_dev = getenv("G16_TRACE_HOST") != nullptr;
+  if (trace_dev) return refresh_timings(P);
+  return G16_OK;
+}
 static int collect_ctx(g16_prover* P, ProofCtx& c, Partial& out) {
   int rc = collect_witness_msms(P, c, out);
   if (rc) return rc;
@@ -778,12 +809,16 @@ static int collect_ctx(g16_prover* P, ProofCtx& c, Partial& out) {
 static int collect_and_assemble(g16_prover* P, ProofCtx& c, const Blinding& bl, g16_proof* out) {
   Partial part;
   int rc = collect_witness_msms(P, c, part);
+  trace_tail("witness sums folded");
   EarlyTail e;
   if (!rc) assemble_early(&P->kp, bl, part.A, part.B1, part.B2, e);   // host work while the H-MSM finishes
+  trace_tail("pi_a, pi_b assembled");
   const int rch = collect_h_msm(P, c, part);                           // always drain what was launched
+  trace_tail("H sum folded, streams drained");
   if (rc) return rc;
   if (rch) return rch;
   assemble_late(e, part.C, part.H, out);
+  trace_tail("pi_c assembled");
   return G16_OK;
 }
 
@@ -1114,6 +1149,10 @@ int g16_get_info(const g16_prover* p, g16_info* o) {
 
 int g16_get_timings(const g16_prover* p, g16_timings* o) {
   if (!p || !o) { set_error("NULL argument"); return G16_E_ARG; }
+  g16_prover* P = const_cast<g16_prover*>(p);   // (reads events only; the handle's results are untouched)
+  std::lock_guard<std::mutex> lk(P->mu);
+  int rc = refresh_timings(P);
+  if (rc) return rc;
   *o = p->tm;
   return G16_OK;
 }
