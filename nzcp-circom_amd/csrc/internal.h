@@ -4,6 +4,7 @@
 #include <stddef.h>
 #include <stdint.h>
 #include <string.h>
+#include <functional>
 #include <string>
 #include <vector>
 
@@ -223,7 +224,10 @@ int msm_launch_lanes(const MsmGroup& g, MsmWorkspace* ws, hipStream_t st, hipStr
                      hipEvent_t gate2);
 void msm_set_quota(MsmWorkspace* ws, uint32_t quota_g1, uint32_t quota_g2);   // accumulate wavefronts retire after this many chunks of 64 tasks (0 = persistent)
 hipEvent_t msm_event(MsmWorkspace* ws, int which);   // 0 = sort done, 1 / 2 = G1 accumulate kernel started / done, 3 / 4 = G1 / G2 lane done (nullptr: no such lane)
-int msm_collect(const MsmGroup& g, MsmWorkspace* ws, MsmResult* out);
+// after_g1 (optional) runs once the G1 sums are folded and BEFORE the wait for the G2 lane: host work that needs only
+// the G1 results overlaps the G2 lane's last kernels (prover.cpp: the G1 half of the proof assembly)
+int msm_collect(const MsmGroup& g, MsmWorkspace* ws, MsmResult* out,
+                const std::function<void(const MsmResult&)>* after_g1 = nullptr);
 double trace_ms();   // G16_TRACE_HOST: milliseconds since the last proof was launched (prover.cpp)
 float msm_last_accum_ms(const MsmWorkspace* ws, int lane);        // lane 0 = G1, 1 = G2: the accumulate kernel alone
 void msm_set_dup_wide(MsmWorkspace* ws, const MsmGroup& g, bool wide);   // chunk width of the repeated values for the next launch (MsmGroup::dup_chunk / dup_chunk_wide)

@@ -1222,7 +1222,7 @@ hipEvent_t msm_event(MsmWorkspace* ws, int which) {
   }
 }
 
-int msm_collect(const MsmGroup& g, MsmWorkspace* ws, MsmResult* out) {
+int msm_collect(const MsmGroup& g, MsmWorkspace* ws, MsmResult* out, const std::function<void(const MsmResult&)>* after_g1) {
   for (auto& p : out->g1) xyzz_set_inf(p);
   xyzz_set_inf(out->g2);
   if (!ws->launched || ws->empty) return G16_OK;
@@ -1270,6 +1270,7 @@ int msm_collect(const MsmGroup& g, MsmWorkspace* ws, MsmResult* out) {
         msm_combine_windows<FqOps>(out->g1[s], rs, g.W, g.c, g.ones);
         if (g.dup_rows && !merged) msm_add_bit_sums<FqOps>(out->g1[s], dup, ws->dup_chunk, ws->dup_bit_rows);
       }
+      if (after_g1 && *after_g1) (*after_g1)(*out);
     } else {
       const G2XYZZ* rows = reinterpret_cast<const G2XYZZ*>(ln.h_pinned);
       std::vector<G2XYZZ> folded;
@@ -1299,7 +1300,7 @@ int msm_collect(const MsmGroup& g, MsmWorkspace* ws, MsmResult* out) {
     int rc = msm_launch_front(g, ws, ws->d_scalars, ws->st_last);
     if (!rc) rc = msm_launch_lanes(g, ws, ws->st_last, ws->st2_last, nullptr, nullptr);
     if (rc) return rc;
-    return msm_collect(g, ws, out);
+    return msm_collect(g, ws, out, after_g1);
   }
   return G16_OK;
 }

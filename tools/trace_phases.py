@@ -10,7 +10,16 @@ def main():
     path = sys.argv[1]
     skip = int(sys.argv[2]) if len(sys.argv) > 2 else 3
     blocks, cur = [], {}
+    tails, tcur = [], {}
     for line in open(path):
+        if line.startswith("[g16 tail]"):   # the host's second half of the proof: "<what> at <ms> ms"
+            m = re.match(r"\[g16 tail\] (.*) at ([\d.]+) ms", line)
+            if m:
+                tcur[m.group(1)] = float(m.group(2))
+                if m.group(1) == "pi_c assembled":
+                    tails.append(tcur)
+                    tcur = {}
+            continue
         if not line.startswith("[g16 dev]"):
             continue
         body = line[len("[g16 dev]"):].strip()
@@ -46,6 +55,10 @@ def main():
     if "W2" in blocks[0]:
         v = [avg(lambda b, i=i: b["W2"][i]) for i in range(6)]
         print(f"  W2 (G2 lane): queue@{v[0]:.3f} accumulate {v[2] - v[1]:.3f} combine {v[3] - v[2]:.3f} reduce {v[4] - v[3]:.3f} tree+copy {v[5] - v[4]:.3f} | end {v[5]:.3f}")
+    tails = tails[skip:]
+    if tails:
+        keys = [k for k in tails[0] if all(k in t for t in tails)]
+        print("  host (ms since the launch began): " + "; ".join(f"{k} {sum(t[k] for t in tails) / len(tails):.3f}" for k in keys))
 
 
 if __name__ == "__main__":
