@@ -233,3 +233,69 @@ def test_both_bucket_reduces_on_every_lane(amd, monkeypatch, scan, c):
     w = f.read_wtns(wt)["w"]
     monkeypatch.setenv("G16_REDUCE_SCAN", scan)
     _prove_both(amd, zkb, w, 7, 9, window_bits=c)
+
+
+def _repeated_value_witness(n, seed):
+    """A witness in the shape that takes the repeated-value rows (MsmGroup::dup_rows): a few dozen full-width values shared
+    by 8..300 points each, byte-sized values shared by many, values shared by fewer than kDupMin = 8 points (they stay on the
+    digit rows), zeros and ones.  Not a satisfying assignment: parity of the arithmetic only."""
+    rnd = random.Random(seed)
+    pool = [rnd.randrange(b.R) for _ in range(40)] + [rnd.randrange(256) for _ in range(30)] + [b.R - 1, (b.R - 1) // 2]
+    rare = [rnd.randrange(b.R) for _ in range(50)]
+    w = [1]
+    while len(w) < n:
+        k = rnd.random()
+        if k < 0.45:
+            w.append(rnd.choice(pool))
+        elif k < 0.50:
+            w.append(rnd.choice(rare))
+        elif k < 0.60:
+            w.append(rnd.randrange(b.R))
+        elif k < 0.80:
+            w.append(0)
+        else:
+            w.append(1)
+    return w
+
+
+@pytest.mark.parametrize("c,chunk,copy", [(13, None, None), (13, "16", None), (11, None, "1"), (16, None, None), (12, "8", None),
+                                          (14, "5", None)])
+def test_repeated_value_rows_in_every_chunk_width(amd, monkeypatch, c, chunk, copy):
+    """Points that share a scalar value enter their section's repeated-value rows once per value; the device multiplies each
+    bucket sum by the chunks of its value and the host folds the chunk sums -- merged into the window sums when the chunks are
+    as wide as the windows (the default for c <= 16: ONE Horner pass), by a second Horner pass otherwise (G16_DUP_CHUNK; the
+    batch pipeline's 16-bit chunks).  Every combination must give the oracle's proof, from g16_prove and from g16_prove_batch,
+    also with the row sums copied from a device buffer (G16_ROWS_COPY: r02's path) instead of written to pinned memory."""
+    import ctypes as C
+    n, p, m = 4000, 4, 2000
+    zkb, _, _ = amd.synth_setup(n, p, m, 91)
+    w = _repeated_value_witness(n, 92)
+    if chunk:
+        monkeypatch.setenv("G16_DUP_CHUNK", chunk)
+    if copy:
+        monkeypatch.setenv("G16_ROWS_COPY", copy)
+    zk = f.read_zkey(zkb)
+    prover = amd.Prover(zkb, window_bits=c)
+    wt = f.write_wtns(w)
+    (A, B, Cc), opub = g.prove(zk, w, 7, 9)
+    want = f.proof_obj(A, B, Cc)
+    proof, pub = prover.prove(wt, f.le(7), f.le(9))
+    assert proof == want and pub == [str(x) for x in opub]
+    tm = prover.timings()           # read lazily from the events of the proof just made
+    assert 0 < tm["qap_ms"] < tm["total_ms"] < 1e3 and tm["msm_ms"][4] > 0, tm
+    # the batch pipeline (its own chunk width; more proofs than contexts)
+    count = 5
+    arr = (C.c_char_p * count)(*([wt] * count))
+    lens = (C.c_size_t * count)(*([len(wt)] * count))
+    rs = b"".join(f.le(7) + f.le(9) for _ in range(count))
+    out = (amd.Proof * count)()
+    pubs = C.create_string_buffer(count * p * 32)
+    rc = amd.load().g16_prove_batch(prover._h, arr, lens, count, rs, out, pubs)
+    assert rc == 0, amd.load().g16_last_error()
+    for i in range(count):
+        assert amd.proof_to_obj(out[i]) == want, i
+    assert prover.timings()["total_ms"] > 0
+    # ... and a single proof again on the same handle (the chunk width is chosen per launch)
+    proof, _ = prover.prove(wt, f.le(7), f.le(9))
+    assert proof == want
+    prover.close()
