@@ -741,29 +741,37 @@ __global__ __launch_bounds__(F::kReduceThreads) void msm_bucket_reduce_kernel(co
 //     sum V_x + step * (sum of the suffix sums of W at the pairs where the weight steps) + f(0) * sum W_x, canonical;
 //   else (the H-MSM's one row of 2^19 buckets: 256 pairs): the triple (P = sum V_x, Y = that sum of suffix sums,
 //     Wt = sum W_x) per group; the host adds sum P + step Y + sum_q F(group q) Wt_q (msm_fold_row: a few dozen additions).
+// The triples variant runs as TWO wavefronts per four groups (gridDim.x = 2 x the group blocks): one sums the V_x (a 4-step tree),
+// the other scans the W_x and sums the selected suffix sums (4 + 4 steps) -- 8 dependent additions on the proof's critical path
+// instead of 12 in one wavefront, which cannot overlap them (a lone wavefront issues a multiply-add every ~11 cycles whatever
+// the independent work at hand, fq29.cuh).
 template <class F, bool FINAL>
 __global__ __launch_bounds__(64) void msm_pairs_fold_kernel(const XYZZ<F>* __restrict__ pairs, MsmReducePlan rp,
                                                             uint32_t ngroups,
                                                             XYZZ<typename F::CanonOps>* __restrict__ out) {
   __builtin_amdgcn_s_setprio(3);   // issue priority over the throughput kernels sharing the SIMD (msm.cuh, kLatencyPrio)
   const uint32_t lane = threadIdx.x, k = lane & (kPairGroup - 1u), nwg = rp.nwg;
-  const uint32_t gid = blockIdx.x * (64u / kPairGroup) + lane / kPairGroup;   // FINAL: the row; else: (row, group)
+  const uint32_t nblk = FINAL ? gridDim.x : gridDim.x / 2u;
+  const bool sum_v = FINAL || blockIdx.x < nblk, scan_w = FINAL || blockIdx.x >= nblk;   // (block-uniform)
+  const uint32_t gid = (blockIdx.x % nblk) * (64u / kPairGroup) + lane / kPairGroup;   // FINAL: the row; else: (row, group)
   const uint32_t row = FINAL ? gid : gid / ngroups, grp = FINAL ? 0u : gid % ngroups;
   const bool live = row < rp.rows;
   const int kind = msm_row_kind(rp, live ? row : 0u);
   const uint32_t step_log = msm_row_step_log(rp, kind);
   const uint32_t x = grp * kPairGroup + k;
   XYZZ<F> v, t;
+  x29_set_inf(v);
+  x29_set_inf(t);
   if (live && x < nwg) {
-    v = pairs[2 * ((size_t)row * nwg + x)];
-    t = pairs[2 * ((size_t)row * nwg + x) + 1];
-  } else {
-    x29_set_inf(v);
-    x29_set_inf(t);
+    if (sum_v) v = pairs[2 * ((size_t)row * nwg + x)];
+    if (scan_w) t = pairs[2 * ((size_t)row * nwg + x) + 1];
   }
-  for (int d = 1; d < (int)kPairGroup; d <<= 1) x29_scan_step<F, (int)kPairGroup>(t, d, k, kPairGroup);
-  XYZZ<F> y = t;
-  if (!(kind != 1 && k >= 1u && (x & ((1u << step_log) - 1u)) == 0u)) x29_set_inf(y);
+  XYZZ<F> y;
+  x29_set_inf(y);
+  if (scan_w) {
+    for (int d = 1; d < (int)kPairGroup; d <<= 1) x29_scan_step<F, (int)kPairGroup>(t, d, k, kPairGroup);
+    if (kind != 1 && k >= 1u && (x & ((1u << step_log) - 1u)) == 0u) y = t;
+  }
   if (FINAL) {
     const uint64_t step = msm_pair_weight(rp, kind, 1ull << step_log) - msm_pair_weight(rp, kind, 0);   // a power of two
     for (uint64_t m = step; m > 1; m >>= 1) x29_dbl(y);
@@ -776,19 +784,22 @@ __global__ __launch_bounds__(64) void msm_pairs_fold_kernel(const XYZZ<F>* __res
       out[row] = r;
     }
   } else {
-    for (int d = (int)kPairGroup >> 1; d >= 1; d >>= 1) {
-      x29_tree_step<F, (int)kPairGroup>(v, d, k);
-      x29_tree_step<F, (int)kPairGroup>(y, d, k);
-    }
-    if (k == 0 && live) {
-      XYZZ<typename F::CanonOps>* o = out + 3 * ((size_t)row * ngroups + grp);
-      XYZZ<typename F::CanonOps> r;
-      x29_to_canon<F, typename F::CanonOps>(r, v);
-      o[0] = r;
-      x29_to_canon<F, typename F::CanonOps>(r, y);
-      o[1] = r;
-      x29_to_canon<F, typename F::CanonOps>(r, t);
-      o[2] = r;
+    XYZZ<typename F::CanonOps>* o = out + 3 * ((size_t)row * ngroups + grp);
+    XYZZ<typename F::CanonOps> r;
+    if (sum_v) {
+      for (int d = (int)kPairGroup >> 1; d >= 1; d >>= 1) x29_tree_step<F, (int)kPairGroup>(v, d, k);
+      if (k == 0 && live) {
+        x29_to_canon<F, typename F::CanonOps>(r, v);
+        o[0] = r;
+      }
+    } else {
+      for (int d = (int)kPairGroup >> 1; d >= 1; d >>= 1) x29_tree_step<F, (int)kPairGroup>(y, d, k);
+      if (k == 0 && live) {
+        x29_to_canon<F, typename F::CanonOps>(r, y);
+        o[1] = r;
+        x29_to_canon<F, typename F::CanonOps>(r, t);
+        o[2] = r;
+      }
     }
   }
 }
@@ -1103,7 +1114,7 @@ int msm_launch_lane_t(const MsmGroup& g, MsmWorkspace* ws, MsmLaneWs& ln, const 
       if (ngroups == 1)
         msm_pairs_fold_kernel<FT, true><<<(ln.rows + gpw - 1) / gpw, 64, 0, st>>>((const TPT*)ln.d_seg, rp, 1u, (CPT*)ln.d_canon);
       else
-        msm_pairs_fold_kernel<FT, false><<<(ln.rows * ngroups + gpw - 1) / gpw, 64, 0, st>>>((const TPT*)ln.d_seg, rp, ngroups,
+        msm_pairs_fold_kernel<FT, false><<<2 * ((ln.rows * ngroups + gpw - 1) / gpw), 64, 0, st>>>((const TPT*)ln.d_seg, rp, ngroups,
                                                                                             (CPT*)ln.d_canon);
     }
   } else {
