@@ -186,7 +186,7 @@ struct MsmGroup {
   // shards of it (profiles/r03_sweeps.txt 10, 17), no gain either way
   // dup_chunk = the window width when c <= 16 (then the chunk sums join the window sums and the host runs ONE Horner pass,
   // msm_collect); dup_chunk_wide = 16, fewer rows of device work: the batch pipeline, which is device-bound, uses it
-  // (msm_set_dup_wide).  dup_rows_cap = the larger row count of the two (buffer sizes).
+  // (msm_set_throughput).  dup_rows_cap = the larger row count of the two (buffer sizes).
   uint32_t dup_chunk = 16, dup_chunk_wide = 16, dup_rows_cap = 16;
   uint32_t rps = 0, rows = 0;   // rows per section (W + ones + dup_rows), rows in total
   uint32_t task_len = 0;        // of the G1 lane
@@ -230,7 +230,9 @@ int msm_collect(const MsmGroup& g, MsmWorkspace* ws, MsmResult* out,
                 const std::function<void(const MsmResult&)>* after_g1 = nullptr);
 double trace_ms();   // G16_TRACE_HOST: milliseconds since the last proof was launched (prover.cpp)
 float msm_last_accum_ms(const MsmWorkspace* ws, int lane);        // lane 0 = G1, 1 = G2: the accumulate kernel alone
-void msm_set_dup_wide(MsmWorkspace* ws, const MsmGroup& g, bool wide);   // chunk width of the repeated values for the next launch (MsmGroup::dup_chunk / dup_chunk_wide)
+// throughput mode of the next launch (the batch pipeline): 16-bit chunks of the repeated values (MsmGroup::dup_chunk_wide) and
+// longer reduce segments on dense rows (MsmLaneWs::seg_len_thr) -- fewer instructions, longer chains
+void msm_set_throughput(MsmWorkspace* ws, const MsmGroup& g, bool on);
 void msm_set_waves(MsmWorkspace* ws, uint32_t waves_g1, uint32_t waves_g2);   // persistent accumulate grids, wavefronts per SIMD (0 = full occupancy)
 float msm_event_offset_ms(MsmWorkspace* ws, hipEvent_t base, int lane, int which);   // G16_TRACE_HOST timeline
 

@@ -93,7 +93,8 @@ struct MsmLaneWs {
   uint32_t* h_stat = nullptr;        // pinned: [0] = end, [1] = start of the lane's sorted entries in the last launch;
                                      // [2] != 0: that launch needed this many tasks, more than max_tasks; [3] != 0: its
                                      // medium / heavy bucket lists overflowed (both: msm_collect fails with G16_E_STATE)
-  uint32_t seg_len = 0;              // buckets per reduce segment (a power of two)
+  uint32_t seg_len = 0;              // buckets per reduce segment (a power of two) of the NEXT launch: seg_len_lat, or
+  uint32_t seg_len_lat = 0, seg_len_thr = 0;   // seg_len_thr in throughput mode (msm_set_throughput)
   uint32_t row_pts = 0;              // canonical points the row block of d_canon / h_pinned holds: `rows` row sums, or
                                      // rows * ngroups * 3 triples when a row is cut into several workgroups (msm_reduce_plan)
   uint32_t* d_off = nullptr;         // [nbk + 1] first sorted entry of a bucket (absolute position in d_sorted)
@@ -154,7 +155,7 @@ struct MsmWorkspace {
   // single-pass front end (dense single-row groups, msm_bin_direct_kernel): (row, bin) regions of bin_cap entries in d_tmp
   bool direct = false;
   uint32_t bin_cap = 0;
-  uint32_t dup_chunk = 16, dup_bit_rows = 16;   // chunk width of the repeated values for the next launch (msm_set_dup_wide)
+  uint32_t dup_chunk = 16, dup_bit_rows = 16;   // chunk width of the repeated values for the next launch (msm_set_throughput)
   uint32_t* h_over = nullptr;        // pinned: != 0 when a bin overflowed in the last launch (msm_collect repeats it two-pass)
   hipStream_t st_last = nullptr, st2_last = nullptr;   // streams of the running launch (for that repeat)
   MsmLaneWs lane[2];

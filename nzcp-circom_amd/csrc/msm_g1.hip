@@ -980,6 +980,17 @@ static int lane_create(MsmLaneWs& ln, const MsmGroup& g, int curve, uint32_t key
     const int force = getenv("G16_REDUCE_SCAN") ? atoi(getenv("G16_REDUCE_SCAN")) : -1;   // (read per handle: tests flip it)
     ln.reduce_scan = force < 0 ? g.dense : force != 0;
   }
+  // Throughput mode (g16_prove_batch: the device is the bottleneck, not the depth of a proof's chains): dense rows take
+  // segments twice as long -- (32 + 19) / 16 additions per bucket instead of (16 + 19) / 8, a quarter of the reduce's
+  // instructions less, on half the wavefronts: H reduce 0.36 -> 0.50 ms for a single proof, 512-proof batches 305-307 ->
+  // 311-312 proofs/s (profiles/r03_sweeps.txt 20).  Buffers are sized for the shorter segments.
+  ln.seg_len_lat = ln.seg_len_thr = ln.seg_len;
+  if (ln.reduce_scan && g.dense && !getenv("G16_SEG_LEN")) {
+    uint32_t t = ln.seg_len * 2;
+    if (g.salt_bits)
+      while (t > ln.seg_len && (t > (1u << g.salt_bits) || ((1u << g.salt_bits) % t) != 0)) t >>= 1;
+    if (t * 64u <= g.B) ln.seg_len_thr = t;   // (a row of at least one wavefront of segments)
+  }
   const MsmReducePlan rp = msm_reduce_plan(g, ln);
   if (ln.reduce_scan) {
     G16_HIP(hipMalloc(&ln.d_seg, 2 * (size_t)ln.rows * rp.nwg * pb + 256));
@@ -1041,7 +1052,7 @@ int msm_workspace_create(MsmWorkspace** out, const MsmGroup& g) {
   MsmWorkspace* ws = new MsmWorkspace();
   *out = ws;
   if (g.n == 0) return G16_OK;
-  msm_set_dup_wide(ws, g, false);
+  msm_set_throughput(ws, g, false);
   const uint32_t nrb = g.rows * g.bins;
   ws->nb = g.rows * g.B;
   G16_HIP(hipMalloc(&ws->d_hist, ((size_t)g.chunks * nrb + 4) * 4));
@@ -1306,10 +1317,12 @@ int msm_collect(const MsmGroup& g, MsmWorkspace* ws, MsmResult* out, const std::
 }
 
 float msm_last_accum_ms(const MsmWorkspace* ws, int lane) { return ws->lane[lane & 1].last_accum_ms; }
-void msm_set_dup_wide(MsmWorkspace* ws, const MsmGroup& g, bool wide) {
+void msm_set_throughput(MsmWorkspace* ws, const MsmGroup& g, bool on) {
   if (!ws) return;
-  ws->dup_chunk = wide ? g.dup_chunk_wide : g.dup_chunk;
+  ws->dup_chunk = on ? g.dup_chunk_wide : g.dup_chunk;
   ws->dup_bit_rows = (254 + ws->dup_chunk - 1) / ws->dup_chunk;
+  for (auto& ln : ws->lane)
+    if (ln.active) ln.seg_len = on ? ln.seg_len_thr : ln.seg_len_lat;
 }
 void msm_set_waves(MsmWorkspace* ws, uint32_t waves_g1, uint32_t waves_g2) {
   ws->lane[0].waves_per_simd = waves_g1;

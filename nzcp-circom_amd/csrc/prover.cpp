@@ -699,12 +699,14 @@ static int launch_h_lanes(g16_prover* P, ProofCtx& c, bool w_launched) {
   return G16_OK;
 }
 // `pipelined`: one of several proofs in flight (g16_prove_batch) -- the device is then the bottleneck, not the host's
-// share of one proof, and the repeated-value stage runs in its cheaper-on-the-device form (MsmGroup::dup_chunk_wide)
+// share of one proof nor the depth of its chains: the repeated-value stage and the H-MSM's bucket reduce run in their
+// cheaper-on-the-device forms (msm_set_throughput: MsmGroup::dup_chunk_wide, MsmLaneWs::seg_len_thr)
 static int launch_ctx(g16_prover* P, ProofCtx& c, const Fr* d_w, bool pipelined = false) {
   G16_HIP(hipSetDevice(P->device));
   int rc;
-  msm_set_dup_wide(c.ws[0], P->grp[0], pipelined);
-  if (P->b2_solo) msm_set_dup_wide(c.ws[2], P->grp[2], pipelined);
+  msm_set_throughput(c.ws[0], P->grp[0], pipelined);
+  msm_set_throughput(c.ws[1], P->grp[1], pipelined);
+  if (P->b2_solo) msm_set_throughput(c.ws[2], P->grp[2], pipelined);
   const auto th0 = std::chrono::steady_clock::now();
   g_trace_origin = th0;
   if (P->tm_ctx == (int)(&c - P->ctx)) P->tm_ctx = -1;   // (its events are about to be recorded again)
