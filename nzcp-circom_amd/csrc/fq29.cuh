@@ -130,6 +130,33 @@ template <int K, class C = Fq29C> G16_HD F29 f29_neg(const F29& b) {
   return r;
 }
 
+// acc + a * b as ONE v_mad_u64_u32 whose addend is the running column sum (-DG16_F29_CHAIN_MADS; off).  Written in C,
+// `acc += (uint64_t)a * b` over a column that starts from the previous column's carry, the compiler reassociates: it starts every
+// column in a fresh accumulator (a shorter dependency chain) and adds the shifted carry afterwards -- 16 v_lshl_add_u64 per
+// product, 7 % of its instructions.  The inline-asm form pins ONE chain: 214 instructions per product instead of 228.  Measured
+// (r03, profiles/r03_sweeps.txt 21), in the throughput kernels only (the tail kernels' products keep CHAIN = false: a wavefront
+// alone on its SIMD needs the shorter chains -- H bucket reduce 0.43 ms against 0.36 with chained products): every stage alone
+// is 0-3 % faster (H accumulate 1.03 -> 1.00 ms, serial sum 6.45 -> 6.32), 768-proof batches +2 % (308 -> 315 proofs/s) -- and a
+// single proof in the product schedule 0.2 ms SLOWER (3.55 -> 3.78 ms: every accumulate and the NTT lengthen by 8-25 % when they
+// share the chip).  The single proof is the headline; the option stays off.
+#if defined(__HIP_DEVICE_COMPILE__) && defined(G16_F29_CHAIN_MADS)
+#define G16_F29_CHAIN 1
+__device__ __forceinline__ uint64_t f29_mad(uint32_t a, uint32_t b, uint64_t acc) {
+  uint64_t r;
+  asm("v_mad_u64_u32 %0, vcc, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(acc) : "vcc");
+  return r;
+}
+// ... with a compile-time constant (a limb of p) in a scalar register
+__device__ __forceinline__ uint64_t f29_mad_k(uint32_t a, uint32_t k, uint64_t acc) {
+  uint64_t r;
+  asm("v_mad_u64_u32 %0, vcc, %1, %2, %3" : "=v"(r) : "v"(a), "s"(k), "v"(acc) : "vcc");
+  return r;
+}
+#else
+G16_HD uint64_t f29_mad(uint32_t a, uint32_t b, uint64_t acc) { return acc + (uint64_t)a * b; }
+G16_HD uint64_t f29_mad_k(uint32_t a, uint32_t k, uint64_t acc) { return acc + (uint64_t)a * k; }
+#endif
+
 // Operand-scanning (row-wise) Montgomery product: the same 162 multiply-adds as f29_mul below, but each
 // goes to a DIFFERENT 64-bit column accumulator than its neighbours (18 short dependency chains instead
 // of 17 long ones), so one wavefront keeps several v_mad_u64_u32 in flight.  Column bound: 9 a*b terms
@@ -197,34 +224,35 @@ template <class C = Fq29C> G16_HD F29 f29_sqr_rows(const F29& a) {
 // The a*b terms and the m*p terms of a column go to two independent 64-bit accumulators (each
 // < 2^63), so a wave that is alone on its SIMD (the reduce kernels, G2) has two mad chains in
 // flight instead of one 162-long dependency chain (measured: 12 cycles/mad dependent vs 5.5 issue).
-template <class C = Fq29C> G16_HD F29 f29_mul(const F29& a, const F29& b) {
+template <class C = Fq29C, bool CHAIN = true> G16_HD F29 f29_mul(const F29& a, const F29& b) {
   G16_F29_ASSERT_LIMBS(a); G16_F29_ASSERT_LIMBS(b);
-#if defined(G16_F29_NO_ILP)
-  {  // experiment: one accumulator, 16 fewer 64-bit adds per product
+#if defined(G16_F29_CHAIN)
+  if constexpr (CHAIN) {  // one accumulator, one dependency chain (see f29_mad)
     uint64_t acc = 0;
     uint32_t m[9];
     F29 r;
 #pragma unroll
     for (int k = 0; k < 9; k++) {
 #pragma unroll
-      for (int i = 0; i <= k; i++) acc += (uint64_t)a.l[i] * b.l[k - i];
+      for (int i = 0; i <= k; i++) acc = f29_mad(a.l[i], b.l[k - i], acc);
 #pragma unroll
-      for (int i = 0; i < k; i++) acc += (uint64_t)m[i] * C::P[k - i];
+      for (int i = 0; i < k; i++) acc = f29_mad_k(m[i], C::P[k - i], acc);
       m[k] = ((uint32_t)acc * C::INV) & kM29;
-      acc += (uint64_t)m[k] * C::P[0];
+      acc = f29_mad_k(m[k], C::P[0], acc);
       acc >>= 29;
     }
 #pragma unroll
     for (int k = 9; k < 17; k++) {
 #pragma unroll
-      for (int i = k - 8; i <= 8; i++) acc += (uint64_t)a.l[i] * b.l[k - i];
+      for (int i = k - 8; i <= 8; i++) acc = f29_mad(a.l[i], b.l[k - i], acc);
 #pragma unroll
-      for (int i = k - 8; i <= 8; i++) acc += (uint64_t)m[i] * C::P[k - i];
+      for (int i = k - 8; i <= 8; i++) acc = f29_mad_k(m[i], C::P[k - i], acc);
       r.l[k - 9] = (uint32_t)acc & kM29;
       acc >>= 29;
     }
     r.l[8] = (uint32_t)acc;
     r.pad_ = 0;
+    G16_F29_ASSERT_BOUND(r);
     return r;
   }
 #endif
@@ -260,11 +288,43 @@ template <class C = Fq29C> G16_HD F29 f29_mul(const F29& a, const F29& b) {
 }
 // a^2 / 2^261: the cross terms a_i a_j (i < j) are taken once against the doubled limb 2 a_i, so
 // 45 product terms instead of 81 (a column still sums below 2^63: 4 * 2^59 + 2^58 + 9 * 2^58).
-template <class C = Fq29C> G16_HD F29 f29_sqr(const F29& a) {
+template <class C = Fq29C, bool CHAIN = true> G16_HD F29 f29_sqr(const F29& a) {
   G16_F29_ASSERT_LIMBS(a);
   uint32_t a2[9];
 #pragma unroll
   for (int i = 0; i < 9; i++) a2[i] = a.l[i] << 1;
+#if defined(G16_F29_CHAIN)
+  if constexpr (CHAIN) {
+    uint64_t acc = 0;
+    uint32_t m[9];
+    F29 r;
+#pragma unroll
+    for (int k = 0; k < 17; k++) {
+      const int lo = k < 9 ? 0 : k - 8, hi = k < 9 ? k : 8;
+#pragma unroll
+      for (int i = lo; i <= hi; i++) {
+        const int j = k - i;
+        if (i < j) acc = f29_mad(a2[i], a.l[j], acc);
+        else if (i == j) acc = f29_mad(a.l[i], a.l[i], acc);
+      }
+      if (k < 9) {
+#pragma unroll
+        for (int i = 0; i < k; i++) acc = f29_mad_k(m[i], C::P[k - i], acc);
+        m[k] = ((uint32_t)acc * C::INV) & kM29;
+        acc = f29_mad_k(m[k], C::P[0], acc);
+      } else {
+#pragma unroll
+        for (int i = k - 8; i <= 8; i++) acc = f29_mad_k(m[i], C::P[k - i], acc);
+        r.l[k - 9] = (uint32_t)acc & kM29;
+      }
+      acc >>= 29;
+    }
+    r.l[8] = (uint32_t)acc;
+    r.pad_ = 0;
+    G16_F29_ASSERT_BOUND(r);
+    return r;
+  }
+#endif
   uint64_t carry = 0;
   uint32_t m[9];
   F29 r;
@@ -298,10 +358,43 @@ template <class C = Fq29C> G16_HD F29 f29_sqr(const F29& a) {
   return r;
 }
 // (a^2 + c*d) / 2^261 with one reduction (real part of an Fq2 square)
-template <class C = Fq29C> G16_HD F29 f29_sqr_mul(const F29& a, const F29& c, const F29& d) {
+template <class C = Fq29C, bool CHAIN = true> G16_HD F29 f29_sqr_mul(const F29& a, const F29& c, const F29& d) {
   uint32_t a2[9];
 #pragma unroll
   for (int i = 0; i < 9; i++) a2[i] = a.l[i] << 1;
+#if defined(G16_F29_CHAIN)
+  if constexpr (CHAIN) {
+    uint64_t acc = 0;
+    uint32_t m[9];
+    F29 r;
+#pragma unroll
+    for (int k = 0; k < 17; k++) {
+      const int lo = k < 9 ? 0 : k - 8, hi = k < 9 ? k : 8;
+#pragma unroll
+      for (int i = lo; i <= hi; i++) {
+        const int j = k - i;
+        if (i < j) acc = f29_mad(a2[i], a.l[j], acc);
+        else if (i == j) acc = f29_mad(a.l[i], a.l[i], acc);
+        acc = f29_mad(c.l[i], d.l[j], acc);
+      }
+      if (k < 9) {
+#pragma unroll
+        for (int i = 0; i < k; i++) acc = f29_mad_k(m[i], C::P[k - i], acc);
+        m[k] = ((uint32_t)acc * C::INV) & kM29;
+        acc = f29_mad_k(m[k], C::P[0], acc);
+      } else {
+#pragma unroll
+        for (int i = k - 8; i <= 8; i++) acc = f29_mad_k(m[i], C::P[k - i], acc);
+        r.l[k - 9] = (uint32_t)acc & kM29;
+      }
+      acc >>= 29;
+    }
+    r.l[8] = (uint32_t)acc;
+    r.pad_ = 0;
+    G16_F29_ASSERT_BOUND(r);
+    return r;
+  }
+#endif
   uint64_t carry = 0;
   uint32_t m[9];
   F29 r;
@@ -338,7 +431,38 @@ template <class C = Fq29C> G16_HD F29 f29_sqr_mul(const F29& a, const F29& c, co
 
 // (a*b + c*d) / 2^261 with ONE reduction (Fq2 products): 27 terms < 2^58 per column still fit
 // (three independent accumulators: a*b, c*d, m*p).
-template <class C = Fq29C> G16_HD F29 f29_mul2(const F29& a, const F29& b, const F29& c, const F29& d) {
+template <class C = Fq29C, bool CHAIN = true> G16_HD F29 f29_mul2(const F29& a, const F29& b, const F29& c, const F29& d) {
+#if defined(G16_F29_CHAIN)
+  if constexpr (CHAIN) {
+    uint64_t acc = 0;
+    uint32_t m[9];
+    F29 r;
+#pragma unroll
+    for (int k = 0; k < 17; k++) {
+      const int lo = k < 9 ? 0 : k - 8, hi = k < 9 ? k : 8;
+#pragma unroll
+      for (int i = lo; i <= hi; i++) {
+        acc = f29_mad(a.l[i], b.l[k - i], acc);
+        acc = f29_mad(c.l[i], d.l[k - i], acc);
+      }
+      if (k < 9) {
+#pragma unroll
+        for (int i = 0; i < k; i++) acc = f29_mad_k(m[i], C::P[k - i], acc);
+        m[k] = ((uint32_t)acc * C::INV) & kM29;
+        acc = f29_mad_k(m[k], C::P[0], acc);
+      } else {
+#pragma unroll
+        for (int i = k - 8; i <= 8; i++) acc = f29_mad_k(m[i], C::P[k - i], acc);
+        r.l[k - 9] = (uint32_t)acc & kM29;
+      }
+      acc >>= 29;
+    }
+    r.l[8] = (uint32_t)acc;
+    r.pad_ = 0;
+    G16_F29_ASSERT_BOUND(r);
+    return r;
+  }
+#endif
   uint64_t carry = 0;
   uint32_t m[9];
   F29 r;
@@ -573,7 +697,22 @@ struct Fq2x29Ops {
 // complete point addition / doubling per code object so that the hot code of every tail kernel fits the instruction
 // cache (r03: the kernels shrink from 0.5-1.2 MB to 18-33 KB + a 32 KB / 17 KB pair of functions, and a proof gets
 // 0.2 ms SLOWER: profiles/r03_sweeps.txt).
-struct Fq29TailOps : Fq29Ops {};
-struct Fq2x29TailOps : Fq2x29Ops {};
+// r03: under -DG16_F29_CHAIN_MADS (see f29_mad) their PRODUCTS keep the two-accumulator form (CHAIN = false): a wavefront alone
+// on its SIMD does gain from the shorter dependency chains inside a product -- with the single chain the H bucket reduce took
+// 0.43 ms instead of 0.36, the G2 lane's 0.84 instead of 0.63.
+struct Fq29TailOps : Fq29Ops {
+  static G16_HD T mul_add(const T& a, const T& b, const T& c, const T& d) { return f29_mul2<Fq29C, false>(a, b, c, d); }
+  static G16_HD T mul(const T& x, const T& y) { return f29_mul<Fq29C, false>(x, y); }
+  static G16_HD T sqr(const T& x) { return f29_sqr<Fq29C, false>(x); }
+};
+struct Fq2x29TailOps : Fq2x29Ops {
+  static G16_HD T mul(const T& x, const T& y) {
+    const F29 nb = f29_neg<8>(x.b);
+    return T{f29_mul2<Fq29C, false>(x.a, y.a, nb, y.b), f29_mul2<Fq29C, false>(x.a, y.b, x.b, y.a)};
+  }
+  static G16_HD T sqr(const T& x) {
+    return T{f29_sqr_mul<Fq29C, false>(x.a, f29_neg<8>(x.b), x.b), f29_mul<Fq29C, false>(x.a, f29_dbl(x.b))};
+  }
+};
 
 }  // namespace g16
