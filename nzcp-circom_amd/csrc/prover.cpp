@@ -593,7 +593,7 @@ static void trace_host(const char* what, const std::chrono::steady_clock::time_p
             std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
 }
 // ... and the host's second half of a proof (waits, folds, assembly) on the same clock: origin = the last launch_ctx
-static std::chrono::steady_clock::time_point g_trace_origin;
+static thread_local std::chrono::steady_clock::time_point g_trace_origin;   // (per host thread: two handles may prove from two threads)
 namespace g16 {
 double trace_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - g_trace_origin).count(); }
 }
