@@ -141,6 +141,9 @@ int g16_finish_host(const uint8_t* zkey, size_t zkey_len, const uint8_t* partial
 void g16_shard_range(uint32_t total, int32_t rank, int32_t count, uint32_t* lo, uint32_t* hi);
 
 int g16_get_info(const g16_prover* p, g16_info* out);
+/* Device-side phase times of the last proof this handle completed (of the last one collected, after g16_prove_batch).
+ * Read from the proof's HIP events when called -- a proof itself no longer pays for them -- so call it before the next
+ * proof is started on the handle; serialised with the handle's other entry points. */
 int g16_get_timings(const g16_prover* p, g16_timings* out);
 void g16_destroy(g16_prover* p);
 const char* g16_last_error(void);
