@@ -94,9 +94,13 @@ int ntt_join_abc(const F29* a, const F29* b, const F29* c, Fr* p_std, size_t n, 
 struct QapCsr {
   // CSR of zkey section 4 per matrix (0 = A, 1 = B): rows = domainSize
   uint32_t* row_ptr[2] = {nullptr, nullptr};  // [N+1]
-  uint32_t* col[2] = {nullptr, nullptr};      // signal index per record
-  F29* val[2] = {nullptr, nullptr};           // coef * 2^522 (lazy format): one product with the plain witness word
-  size_t nnz[2] = {0, 0};
+  // A row's records are ordered: first those whose coefficient is +1 or -1 (79 % of the real NZCP circuit's 4.2 M records:
+  // they ADD the witness word's Montgomery image, bit 31 of col = minus), then the general ones (a product each)
+  uint32_t* col[2] = {nullptr, nullptr};      // signal index per record (| 0x80000000: coefficient -1, in the +-1 part)
+  uint32_t* mid[2] = {nullptr, nullptr};      // [N] where the general records of a row start (an index into col)
+  uint32_t* vptr[2] = {nullptr, nullptr};     // [N] ... and their first coefficient (an index into val)
+  F29* val[2] = {nullptr, nullptr};           // general records only: coef * 2^522 (lazy format): one product with the plain witness word
+  size_t nnz[2] = {0, 0}, ngen[2] = {0, 0};
   uint32_t N = 0;
   // rows with more than kQapLongRow terms in A or B (the modular-addition rows of a SHA-256 circuit carry
   // ~260): one wavefront each instead of one lane
@@ -106,7 +110,8 @@ struct QapCsr {
 static constexpr uint32_t kQapLongRow = 16;
 static constexpr uint32_t kQapWaveRow = 64;
 // a[c] = sum val*w[col] (lazy Montgomery), b likewise, cc = a*b; w is the standard-form witness
-int qap_eval(const QapCsr& q, const Fr* w_std, F29* a, F29* b, F29* cc, hipStream_t st);
+// w_mont: scratch of q's witness length (filled here: the Montgomery image of every witness word, for the +-1 records)
+int qap_eval(const QapCsr& q, const Fr* w_std, uint32_t n_w, F29* w_mont, F29* a, F29* b, F29* cc, hipStream_t st);
 // canonicity of the staged witness words: *h_flag (pinned) <- lowest index of a word >= r, or 0xffffffff, once `st`
 // has passed this point
 int qap_check_witness(const Fr* w_std, uint32_t n, uint32_t* d_flag, uint32_t* h_flag, hipStream_t st);

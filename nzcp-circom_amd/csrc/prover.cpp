@@ -136,6 +136,7 @@ struct g16_prover {
     hipEvent_t ev[8] = {};
     hipEvent_t mev[3][2] = {};
     F29 *d_a = nullptr, *d_b = nullptr, *d_c = nullptr;   // QAP/NTT vectors, lazy 9x29 format
+    F29* d_wm = nullptr;                                  // Montgomery image of the witness (qap_eval's +-1 records)
     Fr* d_p = nullptr;                                    // H-MSM scalars, standard form
     Fr* d_w = nullptr;                                    // batch mode: this context's witness copy
     uint32_t* d_flag = nullptr;                           // canonicity check of the witness this context proves
@@ -155,7 +156,7 @@ struct g16_prover {
     (void)hipSetDevice(device);
     for (Fr* p : slot_dev) if (p) (void)hipFree(p);
     for (auto& c : ctx) {
-      void* vs[] = {c.d_a, c.d_b, c.d_c, c.d_p, c.d_w, c.d_flag};
+      void* vs[] = {c.d_a, c.d_b, c.d_c, c.d_p, c.d_w, c.d_flag, c.d_wm};
       for (void* p : vs) if (p) (void)hipFree(p);
       if (c.h_flag) (void)hipHostFree(c.h_flag);
       for (auto& w : c.ws) msm_workspace_destroy(w);
@@ -168,6 +169,8 @@ struct g16_prover {
     for (int m = 0; m < 2; m++) {
       if (csr.row_ptr[m]) (void)hipFree(csr.row_ptr[m]);
       if (csr.col[m]) (void)hipFree(csr.col[m]);
+      if (csr.mid[m]) (void)hipFree(csr.mid[m]);
+      if (csr.vptr[m]) (void)hipFree(csr.vptr[m]);
       if (csr.val[m]) (void)hipFree(csr.val[m]);
     }
     if (csr.long_rows) (void)hipFree(csr.long_rows);
@@ -240,19 +243,47 @@ static int build_csr(g16_prover* P, const Section& s4) {
       G16_HIP(hipMemcpy(P->csr.long_rows, long_rows.data(), long_rows.size() * 4, hipMemcpyHostToDevice));
     }
   }
+  // a row's records: the +-1 coefficients first (the file stores coef * R^2 mod r: +1 is R^2, -1 is r - R^2), then the rest
+  Fr one, mone;
+  for (int i = 0; i < 8; i++) one.v[i] = FrParams::R2[i];
+  fp_reduce_once(one);
+  mone = fp_neg(one);
   for (int m = 0; m < 2; m++) {
     const size_t nnz = col[m].size();
+    std::vector<uint32_t> col2(nnz), mid(N), vptr(N);
+    std::vector<Fr> gen;
+    gen.reserve(nnz / 2 + 1);
+    for (uint32_t c = 0; c < N; c++) {
+      uint32_t k2 = rp[m][c];
+      for (uint32_t k = rp[m][c]; k < rp[m][c + 1]; k++) {
+        if (fp_eq(val[m][k], one)) col2[k2++] = col[m][k];
+        else if (fp_eq(val[m][k], mone)) col2[k2++] = col[m][k] | 0x80000000u;
+      }
+      mid[c] = k2;
+      vptr[c] = (uint32_t)gen.size();
+      for (uint32_t k = rp[m][c]; k < rp[m][c + 1]; k++)
+        if (!fp_eq(val[m][k], one) && !fp_eq(val[m][k], mone)) {
+          col2[k2++] = col[m][k];
+          gen.push_back(val[m][k]);
+        }
+    }
+    const size_t ngen = gen.size();
     P->csr.nnz[m] = nnz;
+    P->csr.ngen[m] = ngen;
     G16_HIP(hipMalloc(&P->csr.row_ptr[m], ((size_t)N + 1) * 4));
+    G16_HIP(hipMalloc(&P->csr.mid[m], ((size_t)N + 1) * 4));
+    G16_HIP(hipMalloc(&P->csr.vptr[m], ((size_t)N + 1) * 4));
     G16_HIP(hipMalloc(&P->csr.col[m], (nnz + 1) * 4));
-    G16_HIP(hipMalloc(&P->csr.val[m], (nnz + 1) * sizeof(F29)));
+    G16_HIP(hipMalloc(&P->csr.val[m], (ngen + 1) * sizeof(F29)));
     G16_HIP(hipMemcpy(P->csr.row_ptr[m], rp[m].data(), ((size_t)N + 1) * 4, hipMemcpyHostToDevice));
-    if (nnz) {
-      G16_HIP(hipMemcpy(P->csr.col[m], col[m].data(), nnz * 4, hipMemcpyHostToDevice));
+    G16_HIP(hipMemcpy(P->csr.mid[m], mid.data(), (size_t)N * 4, hipMemcpyHostToDevice));
+    G16_HIP(hipMemcpy(P->csr.vptr[m], vptr.data(), (size_t)N * 4, hipMemcpyHostToDevice));
+    if (nnz) G16_HIP(hipMemcpy(P->csr.col[m], col2.data(), nnz * 4, hipMemcpyHostToDevice));
+    if (ngen) {
       Fr* tmp = nullptr;   // file words -> lazy coefficient format, once
-      G16_HIP(hipMalloc(&tmp, nnz * sizeof(Fr)));
-      G16_HIP(hipMemcpy(tmp, val[m].data(), nnz * sizeof(Fr), hipMemcpyHostToDevice));
-      int rc = qap_convert_coefs(tmp, P->csr.val[m], nnz, P->st);
+      G16_HIP(hipMalloc(&tmp, ngen * sizeof(Fr)));
+      G16_HIP(hipMemcpy(tmp, gen.data(), ngen * sizeof(Fr), hipMemcpyHostToDevice));
+      int rc = qap_convert_coefs(tmp, P->csr.val[m], ngen, P->st);
       if (!rc && hipStreamSynchronize(P->st) != hipSuccess) { set_error("coefficient conversion failed"); rc = G16_E_HIP; }
       (void)hipFree(tmp);
       if (rc) return rc;
@@ -418,6 +449,7 @@ static int create_impl(const uint8_t* zkey, size_t len, const g16_opts* opts, g1
     G16_HIP(hipMalloc(&c.d_b, vb));
     G16_HIP(hipMalloc(&c.d_c, vb));
     G16_HIP(hipMalloc(&c.d_p, (size_t)P->N * sizeof(Fr)));
+    G16_HIP(hipMalloc(&c.d_wm, ((size_t)P->nVars + 1) * sizeof(F29)));
     G16_HIP(hipMalloc(&c.d_flag, 64));
     G16_HIP(hipHostMalloc((void**)&c.h_flag, 64));
     *c.h_flag = 0xffffffffu;
@@ -655,7 +687,7 @@ static int launch_witness_lanes(g16_prover* P, ProofCtx& c, bool h_launched) {
 // 1 = B, 2 = C) on the main stream
 static int launch_qap_ntt(g16_prover* P, ProofCtx& c, const Fr* d_w, uint32_t mask, bool fuse_join = false) {
   int rc;
-  if ((rc = qap_eval(P->csr, d_w, c.d_a, c.d_b, c.d_c, c.st))) return rc;
+  if ((rc = qap_eval(P->csr, d_w, P->nVars, c.d_wm, c.d_a, c.d_b, c.d_c, c.st))) return rc;
   G16_HIP(hipEventRecord(c.ev[3], c.st));
   static const bool mid = !(getenv("G16_NO_FUSED_MID") && atoi(getenv("G16_NO_FUSED_MID")));
   if (fuse_join) {   // all three vectors here: the last forward pass writes P directly
@@ -1185,7 +1217,7 @@ int g16_qap_eval(g16_prover* p, uint32_t slot, uint8_t* a, uint8_t* b, uint8_t* 
   if (slot >= p->slot_dev.size() || !p->slot_dev[slot]) { set_error("witness slot not staged"); return G16_E_STATE; }
   G16_HIP(hipSetDevice(p->device));
   ProofCtx& cx = p->ctx[0];
-  int rc = qap_eval(p->csr, p->slot_dev[slot], cx.d_a, cx.d_b, cx.d_c, cx.st);
+  int rc = qap_eval(p->csr, p->slot_dev[slot], p->nVars, cx.d_wm, cx.d_a, cx.d_b, cx.d_c, cx.st);
   if (rc) return rc;
   const F29* src[3] = {cx.d_a, cx.d_b, cx.d_c};
   uint8_t* dst[3] = {a, b, c};

@@ -25,32 +25,44 @@ __device__ __forceinline__ void qap_set_prio() {
   else if (p >= 3) __builtin_amdgcn_s_setprio(3);
 }
 
-__device__ __forceinline__ void qap_eval_rows(
-    uint32_t block, const uint32_t* __restrict__ rpA, const uint32_t* __restrict__ colA, const F29* __restrict__ valA,
-    const uint32_t* __restrict__ rpB, const uint32_t* __restrict__ colB, const F29* __restrict__ valB,
-    const Fr* __restrict__ w, F29* __restrict__ a, F29* __restrict__ b, F29* __restrict__ cc, uint32_t N) {
+// One matrix as the kernel sees it, and the sum of one row's records [k0, k1) taken with stride `step` from lane offset `lane`:
+// the +-1 records add or subtract the Montgomery image of their witness word (a 40-byte gather and nine limb additions instead
+// of a repack and a 229-instruction product: r03, 79 % of the records), the general ones multiply.  Lazy sums: an added term is
+// below 1.1r, a subtracted one adds 2r - x <= 2r; a weak reduction (-> 1.0001r) whenever seven units have gone in keeps the
+// sum below 1 + 6 * 1.1 + 2 = 9.6r < 16r.
+struct QapMat { const uint32_t *rp, *mid, *vptr, *col; const F29* val; };
+__device__ __forceinline__ F29 qap_row_sum(const QapMat& M, uint32_t c, uint32_t lane, uint32_t step,
+                                            const Fr* __restrict__ w, const F29* __restrict__ wm) {
+  F29 s = f29_zero();
+  uint32_t cnt = 0;
+  const uint32_t k0 = M.rp[c], km = M.mid[c], k1 = M.rp[c + 1];
+  for (uint32_t k = k0 + lane; k < km; k += step) {
+    const uint32_t ci = M.col[k];
+    const F29 x = wm[ci & 0x7fffffffu];
+    if (ci >> 31) { s = fr29_sub<2>(s, x); cnt += 2; }
+    else { s = fr29_add(s, x); cnt += 1; }
+    if (cnt >= 7) { s = fr29_weak_reduce(s); cnt = 0; }
+  }
+  const uint32_t vp = M.vptr[c];
+  for (uint32_t k = km + lane; k < k1; k += step) {
+    s = fr29_add(s, fr29_mul(M.val[vp + (k - km)], fr29_repack(w[M.col[k]])));
+    if (++cnt >= 7) { s = fr29_weak_reduce(s); cnt = 0; }
+  }
+  return s;
+}
+
+__device__ __forceinline__ void qap_eval_rows(uint32_t block, const QapMat& A, const QapMat& B, const Fr* __restrict__ w,
+                                              const F29* __restrict__ wm, F29* __restrict__ a, F29* __restrict__ b,
+                                              F29* __restrict__ cc, uint32_t N) {
   const uint32_t c = block * blockDim.x + threadIdx.x;
   if (c >= N) return;
-  if (rpA[c + 1] - rpA[c] > kQapLongRow || rpB[c + 1] - rpB[c] > kQapLongRow) return;   // qap_long_rows_kernel's
-  // lazy sums: each term is below 1.1r; weak-reduce every 8 terms so the sum stays below 16r
-  F29 sa = f29_zero(), sb = f29_zero();
-  uint32_t cnt = 0;
-  for (uint32_t k = rpA[c], e = rpA[c + 1]; k < e; k++) {
-    sa = fr29_add(sa, fr29_mul(valA[k], fr29_repack(w[colA[k]])));
-    if ((++cnt & 7u) == 0) sa = fr29_weak_reduce(sa);
-  }
-  cnt = 0;
-  for (uint32_t k = rpB[c], e = rpB[c + 1]; k < e; k++) {
-    sb = fr29_add(sb, fr29_mul(valB[k], fr29_repack(w[colB[k]])));
-    if ((++cnt & 7u) == 0) sb = fr29_weak_reduce(sb);
-  }
+  if (A.rp[c + 1] - A.rp[c] > kQapLongRow || B.rp[c + 1] - B.rp[c] > kQapLongRow) return;   // the grouped rows below
+  const F29 sa = qap_row_sum(A, c, 0u, 1u, w, wm), sb = qap_row_sum(B, c, 0u, 1u, w, wm);
   a[c] = sa;
   b[c] = sb;
   cc[c] = fr29_mul(sa, sb);
 }
 
-// One wavefront per long row: lanes stride over the row's records, partial sums meet in a 6-step
-// __shfl_xor tree (weak-reduced on the way so they stay below 16r).
 __device__ __forceinline__ F29 f29_shfl_xor(const F29& v, int mask) {
   F29 r;
 #pragma unroll
@@ -64,26 +76,17 @@ __device__ __forceinline__ F29 f29_shfl_xor(const F29& v, int mask) {
 // whole wavefront per row (r02) those 48 k rows cost 65 M wavefront-instructions -- 4 % of a proof, two 6-step trees over
 // mostly empty lanes each; eight-lane groups do them for a tenth of that.
 template <int GW>
-__device__ __forceinline__ void qap_long_rows(
-    uint32_t block, const uint32_t* __restrict__ rows, uint32_t n_long,
-    const uint32_t* __restrict__ rpA, const uint32_t* __restrict__ colA, const F29* __restrict__ valA,
-    const uint32_t* __restrict__ rpB, const uint32_t* __restrict__ colB, const F29* __restrict__ valB,
-    const Fr* __restrict__ w, F29* __restrict__ a, F29* __restrict__ b, F29* __restrict__ cc) {
+__device__ __forceinline__ void qap_long_rows(uint32_t block, const uint32_t* __restrict__ rows, uint32_t n_long,
+                                              const QapMat& A, const QapMat& B, const Fr* __restrict__ w,
+                                              const F29* __restrict__ wm, F29* __restrict__ a, F29* __restrict__ b,
+                                              F29* __restrict__ cc) {
   const uint32_t tid = block * blockDim.x + threadIdx.x, gid = tid / GW, lane = tid % GW;
   if (gid >= n_long) return;   // (whole groups leave together: the shuffles below stay inside a group)
   const uint32_t c = rows[gid];
-  F29 s[2] = {f29_zero(), f29_zero()};
+  F29 s[2];
 #pragma unroll
   for (int m = 0; m < 2; m++) {
-    const uint32_t* rp = m ? rpB : rpA;
-    const uint32_t* col = m ? colB : colA;
-    const F29* val = m ? valB : valA;
-    uint32_t cnt = 0;
-    for (uint32_t k = rp[c] + lane, e = rp[c + 1]; k < e; k += GW) {
-      s[m] = fr29_add(s[m], fr29_mul(val[k], fr29_repack(w[col[k]])));
-      if ((++cnt & 7u) == 0) s[m] = fr29_weak_reduce(s[m]);
-    }
-    s[m] = fr29_weak_reduce(s[m]);
+    s[m] = fr29_weak_reduce(qap_row_sum(m ? B : A, c, lane, (uint32_t)GW, w, wm));
     for (int d = GW / 2; d >= 1; d >>= 1) {
       s[m] = fr29_add(s[m], f29_shfl_xor(s[m], d));
       if (d == 8 || d == 1) s[m] = fr29_weak_reduce(s[m]);   // at most 8 partials below ~2r between reductions
@@ -101,18 +104,23 @@ __device__ __forceinline__ void qap_long_rows(
 // the rows of 17-64 terms in eight-lane groups, the rest a row per thread.  r02's three back-to-back launches at the head
 // of a proof's critical chain lasted 0.15 ms standalone; side by side they last as long as the longest.
 struct QapRows { const uint32_t* rows; uint32_t n_mid, n_long, nb_long, nb_mid; };
-__global__ __launch_bounds__(256) void qap_eval_kernel(
-    QapRows lr, const uint32_t* __restrict__ rpA, const uint32_t* __restrict__ colA, const F29* __restrict__ valA,
-    const uint32_t* __restrict__ rpB, const uint32_t* __restrict__ colB, const F29* __restrict__ valB,
-    const Fr* __restrict__ w, F29* __restrict__ a, F29* __restrict__ b, F29* __restrict__ cc, uint32_t N) {
+__global__ __launch_bounds__(256) void qap_eval_kernel(QapRows lr, QapMat A, QapMat B, const Fr* __restrict__ w,
+                                                       const F29* __restrict__ wm, F29* __restrict__ a,
+                                                       F29* __restrict__ b, F29* __restrict__ cc, uint32_t N) {
   qap_set_prio();
   const uint32_t blk = blockIdx.x;   // (uniform per block: no divergence between the three bodies)
   if (blk < lr.nb_long)
-    qap_long_rows<64>(blk, lr.rows + lr.n_mid, lr.n_long - lr.n_mid, rpA, colA, valA, rpB, colB, valB, w, a, b, cc);
+    qap_long_rows<64>(blk, lr.rows + lr.n_mid, lr.n_long - lr.n_mid, A, B, w, wm, a, b, cc);
   else if (blk < lr.nb_long + lr.nb_mid)
-    qap_long_rows<8>(blk - lr.nb_long, lr.rows, lr.n_mid, rpA, colA, valA, rpB, colB, valB, w, a, b, cc);
+    qap_long_rows<8>(blk - lr.nb_long, lr.rows, lr.n_mid, A, B, w, wm, a, b, cc);
   else
-    qap_eval_rows(blk - lr.nb_long - lr.nb_mid, rpA, colA, valA, rpB, colB, valB, w, a, b, cc, N);
+    qap_eval_rows(blk - lr.nb_long - lr.nb_mid, A, B, w, wm, a, b, cc, N);
+}
+// wm[i] = Montgomery image of the witness word i (lazy format): what a +-1 record adds
+__global__ __launch_bounds__(256) void qap_witness_mont_kernel(const Fr* __restrict__ w, F29* __restrict__ wm, uint32_t n) {
+  qap_set_prio();
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) wm[i] = fr29_from_plain(w[i]);
 }
 
 __global__ __launch_bounds__(256) void qap_convert_kernel(const Fr* __restrict__ in, F29* __restrict__ out, size_t n) {
@@ -120,7 +128,7 @@ __global__ __launch_bounds__(256) void qap_convert_kernel(const Fr* __restrict__
   if (i < n) out[i] = fr29_from_zkey_coef(in[i]);
 }
 
-int qap_eval(const QapCsr& q, const Fr* w_std, F29* a, F29* b, F29* cc, hipStream_t st) {
+int qap_eval(const QapCsr& q, const Fr* w_std, uint32_t n_w, F29* w_mont, F29* a, F29* b, F29* cc, hipStream_t st) {
   // long_rows = [the n_mid rows of kQapLongRow < terms <= kQapWaveRow][the rows above]
   QapRows lr;
   lr.rows = q.long_rows;
@@ -128,8 +136,9 @@ int qap_eval(const QapCsr& q, const Fr* w_std, F29* a, F29* b, F29* cc, hipStrea
   lr.n_long = q.n_long;
   lr.nb_long = (q.n_long - q.n_mid + 3) / 4;
   lr.nb_mid = (q.n_mid + 31) / 32;
-  qap_eval_kernel<<<lr.nb_long + lr.nb_mid + (q.N + 255) / 256, 256, 0, st>>>(lr, q.row_ptr[0], q.col[0], q.val[0], q.row_ptr[1],
-                                                                              q.col[1], q.val[1], w_std, a, b, cc, q.N);
+  const QapMat A{q.row_ptr[0], q.mid[0], q.vptr[0], q.col[0], q.val[0]}, B{q.row_ptr[1], q.mid[1], q.vptr[1], q.col[1], q.val[1]};
+  if (n_w) qap_witness_mont_kernel<<<(n_w + 255) / 256, 256, 0, st>>>(w_std, w_mont, n_w);
+  qap_eval_kernel<<<lr.nb_long + lr.nb_mid + (q.N + 255) / 256, 256, 0, st>>>(lr, A, B, w_std, w_mont, a, b, cc, q.N);
   G16_HIP(hipGetLastError());
   return G16_OK;
 }

@@ -257,3 +257,37 @@ def test_qap_eval_long_rows(amd):
     for (m, c, s, v) in zk["coefs"]:
         per_row[(m, c)] = per_row.get((m, c), 0) + 1
     assert max(per_row.values()) > 64      # the wavefront path was really exercised
+
+
+def test_qap_eval_plus_minus_one_records(amd):
+    """Records whose coefficient is +1 or -1 (79 % of the real circuit's) add or subtract the Montgomery image of their witness
+    word instead of multiplying (qap_row_sum): rows of only +1, only -1 (long runs of subtractions: the lazy sums' bound), mixed
+    with general coefficients, in all three row shapes (a lane, eight lanes, a wavefront per row), witness words up to r - 1."""
+    import random
+    rnd = random.Random(77)
+    n, p = 600, 3
+    coefs = [1, b.R - 1, 1, b.R - 1, 2, b.R - 2, rnd.randrange(b.R), 1]
+
+    def lin(k, pick):
+        return [(rnd.randrange(n), pick()) for _ in range(k)]
+    rows = []
+    for k in (1, 2, 3, 9, 16):                       # a lane per row
+        rows.append((lin(k, lambda: 1), lin(k, lambda: b.R - 1), []))
+        rows.append((lin(k, lambda: b.R - 1), lin(k, lambda: rnd.choice(coefs)), []))
+    for k in (17, 23, 40, 64):                       # eight lanes per row
+        rows.append((lin(k, lambda: b.R - 1), lin(2, lambda: 1), []))
+        rows.append((lin(k, lambda: rnd.choice(coefs)), lin(k, lambda: rnd.choice(coefs)), []))
+    for k in (65, 130, 300):                         # a wavefront per row
+        rows.append((lin(k, lambda: b.R - 1), lin(k, lambda: 1), []))
+        rows.append((lin(k, lambda: rnd.choice(coefs)), lin(1, lambda: rnd.randrange(b.R)), []))
+    rows += [([], lin(3, lambda: 1), []), (lin(3, lambda: b.R - 1), [], [])]
+    zk, _ = g.setup(n, p, rows, g.trapdoor(78))
+    w = [1] + [rnd.choice([b.R - 1, b.R - 2, rnd.randrange(b.R), rnd.randrange(256), 0, 1]) for _ in range(n - 1)]
+    zkb, wt = f.write_zkey(zk), f.write_wtns(w)
+    _qap_check(amd, zkb, wt)
+    # ... and the whole proof on it (the witness satisfies nothing: parity of the arithmetic)
+    prover = amd.Prover(zkb)
+    proof, pub = prover.prove(wt, f.le(5), f.le(6))
+    prover.close()
+    (A, B, C), opub = g.prove(zk, w, 5, 6)
+    assert proof == f.proof_obj(A, B, C) and pub == [str(x) for x in opub]
